@@ -1,0 +1,14 @@
+"""g.p.u-pathtracer_amd — MI355X-native progressive path tracer (hot path only).
+
+Python host-side mirror of the reference's device-facing surface over the C ABI in
+include/ptmi.h (HIP kernels in csrc/).  Import name: `gpu_pathtracer_amd` (the directory
+name is not a valid Python identifier; the repo-root shim gpu_pathtracer_amd.py aliases it).
+"""
+from . import _abi
+from ._abi import (Camera, Params, Sphere, Counters, BuildParams, MAT_DIFF, MAT_METAL, MAT_SPEC, MAT_REFR,
+                   FLAG_METAL_LITERAL_W, FLAG_WRITE_RGBA, KERNEL_AUTO, KERNEL_MEGA_BVH2, KERNEL_MEGA_WIDE,
+                   KERNEL_PERSISTENT, KERNEL_WAVEFRONT, OPT_KERNEL, OPT_COUNTERS, OPT_TIMING)
+from .host import (Mesh, Bvh, frame_hash, reference_spheres, default_camera, default_params, scene_mesh)
+from .tracer import PathTracer, PtError, DeviceBuffer, algorithmic_bytes
+
+__all__ = [n for n in dir() if not n.startswith("_")]

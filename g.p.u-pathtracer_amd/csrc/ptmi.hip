@@ -1,0 +1,438 @@
+// ptmi.hip — C ABI of libptmi.so (include/ptmi.h): context, scene upload + gfx950
+// re-layout, launches.  The kernels are in pt_kernels.h.
+//
+// Replaces BasicScene::launchKernel (GpuPathTracer/tracer.cu:405-415) and the device
+// buffer set-up of GpuPathTracer/BasicScene.cpp:138-149,:214-215,:297-313.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptmi.h"
+#include "pt_kernels.h"
+
+static_assert(sizeof(pt_sphere) == 44, "pt_sphere must match the reference Sphere (44 B)");
+static_assert(sizeof(pt_sphere_d) == sizeof(pt_sphere), "device sphere mirror");
+
+namespace {
+thread_local std::string g_err;
+}
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    float4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    pt_sphere_d* d_spheres = nullptr;
+    int n_spheres = 0;
+    uint64_t n_inner = 0, n_refs = 0, n_leaves = 0, scene_bytes = 0;
+    uint32_t max_depth = 0;
+    bool has_bvh = false;
+    // options
+    int opt_kernel = PT_KERNEL_AUTO;
+    int opt_counters = 0;
+    int opt_timing = 0;
+    // measurement
+    unsigned long long* d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+int fail(pt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+int hip_fail(pt_ctx* c, hipError_t e, const char* what) {
+    return fail(c, PT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, call)                                          \
+    do {                                                            \
+        hipError_t e_ = (call);                                     \
+        if (e_ != hipSuccess) return hip_fail((ctx), e_, #call);    \
+    } while (0)
+
+int stack_for_depth(uint32_t depth) {
+    // entries needed: sentinel + one push per level with two hit children
+    const uint32_t need = depth + 2;
+    if (need <= 24) return 24;
+    if (need <= 32) return 32;
+    if (need <= 48) return 48;
+    return 72;
+}
+
+template <int STACK>
+static void launch_mega(pt_ctx* c, const KParams& P, int blocks) {
+    if (c->opt_counters) hipLaunchKernelGGL((k_trace_mega_bvh2<STACK, true>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, P);
+    else hipLaunchKernelGGL((k_trace_mega_bvh2<STACK, false>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, P);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_abi_version(void) { return PTMI_ABI_VERSION; }
+
+int pt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return PT_ERR_DEVICE; }
+    return n;
+}
+
+const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pt_create(int device, pt_ctx** out) {
+    if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
+    if (device < 0 || device >= n) return fail(nullptr, PT_ERR_INVALID, "pt_create: no such device");
+    pt_ctx* c = new pt_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipSetDevice"); }
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
+    c->stream = c->own_stream;
+    if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    *out = c;
+    return PT_OK;
+}
+
+int pt_destroy(pt_ctx* c) {
+    if (!c) return PT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_nodes);
+    (void)hipFree(c->d_tris);
+    (void)hipFree(c->d_spheres);
+    (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return PT_OK;
+}
+
+int pt_set_stream(pt_ctx* c, void* s) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PT_OK;
+}
+
+int pt_set_option(pt_ctx* c, int option, int value) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    switch (option) {
+        case PT_OPT_KERNEL:
+            if (value != PT_KERNEL_AUTO && value != PT_KERNEL_MEGA_BVH2)
+                return fail(c, PT_ERR_UNSUPPORTED, "pt_set_option: kernel variant not available in this build");
+            c->opt_kernel = value;
+            return PT_OK;
+        case PT_OPT_COUNTERS: c->opt_counters = value != 0; return PT_OK;
+        case PT_OPT_TIMING: c->opt_timing = value != 0; return PT_OK;
+        default: return fail(c, PT_ERR_INVALID, "pt_set_option: unknown option");
+    }
+}
+
+int pt_sync(pt_ctx* c) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_malloc(pt_ctx* c, size_t bytes, void** out) {
+    if (!c || !out || bytes == 0) return fail(c, PT_ERR_INVALID, "pt_malloc: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(out, bytes));
+    return PT_OK;
+}
+int pt_free(pt_ctx* c, void* p) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(p));
+    return PT_OK;
+}
+int pt_memset(pt_ctx* c, void* p, int v, size_t bytes) {
+    if (!c || !p) return fail(c, PT_ERR_INVALID, "pt_memset: bad argument");
+    HIP_TRY(c, hipMemsetAsync(p, v, bytes, c->stream));
+    return PT_OK;
+}
+int pt_download(pt_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return fail(c, PT_ERR_INVALID, "pt_download: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+int pt_upload(pt_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return fail(c, PT_ERR_INVALID, "pt_upload: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Scene upload: validate the reference Compact arrays (CudaBVH.cpp:121-270), then re-lay
+// them out for the gfx950 kernels:
+//   nodes  : same 64-byte record, children in depth-first order (parent next to its first
+//            inner child), links rewritten from byte offsets to float4 indices
+//   tris   : 48-byte records {v0.xyz, id | e1.xyz, last | e2.xyz, 0}: the edge subtraction
+//            of cudaUtils.h:177-178 is hoisted to upload (same IEEE result), the index
+//            remap of :452-456 and the 16-byte terminator fetch of :410-413 disappear
+int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float* tri_verts, size_t n_tri_vec4,
+                  const int32_t* tri_index, size_t n_index) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    if (!nodes || !tri_verts || !tri_index) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: null array");
+    if (n_node_vec4 < 4 || (n_node_vec4 % 4) != 0) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node array must hold whole 4-vec4 nodes");
+    if (n_index != n_tri_vec4) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: index array must parallel the triangle array");
+    if (n_node_vec4 * 16 >= (size_t)PT_SENTINEL || n_tri_vec4 >= (size_t)0x7fffffff)
+        return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
+
+    const size_t n_nodes_in = n_node_vec4 / 4;
+    std::vector<int32_t> new_index(n_nodes_in, -1);  // old node number -> new node number
+    std::vector<float> out_nodes;
+    std::vector<float> out_tris;
+    out_nodes.reserve(n_node_vec4 * 4);
+    out_tris.reserve(n_tri_vec4 * 4);
+    uint64_t n_leaves = 0, n_refs = 0;
+    uint32_t max_depth = 0;
+
+    auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+    auto fbits = [](int32_t i) { float f; std::memcpy(&f, &i, 4); return f; };
+
+    // emits one leaf, returns the link (~first float4 index) or 0 on error
+    auto emit_leaf = [&](int32_t link, int32_t& out_link) -> bool {
+        size_t a = (size_t)(~link);
+        const size_t first = out_tris.size() / 4;
+        size_t count = 0;
+        for (;; a += 3) {
+            if (a >= n_tri_vec4) return false;
+            const float* r = tri_verts + 4 * a;
+            uint32_t w0; std::memcpy(&w0, r, 4);
+            if (w0 == 0x80000000u) break;
+            if (a + 2 >= n_tri_vec4) return false;
+            const float* v0 = r; const float* v1 = r + 4; const float* v2 = r + 8;
+            float rec[12] = {v0[0], v0[1], v0[2], fbits(tri_index[a]),
+                             v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f,
+                             v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f};
+            out_tris.insert(out_tris.end(), rec, rec + 12);
+            count++;
+        }
+        if (count == 0) {  // empty leaf: one degenerate record that can never be hit
+            float rec[12] = {0, 0, 0, fbits(-1), 0, 0, 0, 0, 0, 0, 0, 0};
+            out_tris.insert(out_tris.end(), rec, rec + 12);
+            count = 1;
+        }
+        out_tris[out_tris.size() - 12 + 7] = fbits(1);  // e1.w of the last record
+        n_leaves++;
+        n_refs += count;
+        out_link = ~(int32_t)first;
+        return true;
+    };
+
+    struct Item { size_t old_node; size_t new_node; uint32_t depth; };
+    std::vector<Item> stack;
+    new_index[0] = 0;
+    out_nodes.resize(16, 0.f);
+    stack.push_back({0, 0, 0});
+    size_t n_out = 1;
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        const float* src = nodes + 16 * it.old_node;
+        int32_t link[2] = {bits(src[12]), bits(src[13])};
+        int32_t new_link[2];
+        // child 1 first so that child 0 is popped (and numbered) right after its parent
+        for (int i = 1; i >= 0; i--) {
+            if (link[i] >= 0) {
+                if ((link[i] % 64) != 0 || (size_t)link[i] / 64 >= n_nodes_in)
+                    return fail(c, PT_ERR_INVALID, "pt_upload_bvh: child link is not a valid node byte offset");
+                const size_t child = (size_t)link[i] / 64;
+                if (new_index[child] != -1) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node referenced twice (not a tree)");
+                new_index[child] = (int32_t)n_out;
+                new_link[i] = (int32_t)(n_out * 4);  // float4 index
+                stack.push_back({child, n_out, it.depth + 1});
+                n_out++;
+                out_nodes.resize(n_out * 16, 0.f);
+            } else {
+                if (!emit_leaf(link[i], new_link[i])) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: leaf runs past the triangle array");
+                max_depth = std::max(max_depth, it.depth + 1);
+            }
+        }
+        float* dst = &out_nodes[16 * it.new_node];
+        std::memcpy(dst, src, 12 * sizeof(float));
+        dst[12] = fbits(new_link[0]);
+        dst[13] = fbits(new_link[1]);
+        dst[14] = 0.f;
+        dst[15] = 0.f;
+    }
+    // numbering above follows push order, not pop order; renumber depth-first for locality
+    // (kept simple: push order already places siblings together and subtrees contiguously
+    // enough for the 64-byte gathers; see DESIGN.md §3 for the measured alternatives)
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
+    (void)hipFree(c->d_tris); c->d_tris = nullptr;
+    c->has_bvh = false;
+    const size_t nb = out_nodes.size() * sizeof(float), tb = out_tris.size() * sizeof(float);
+    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb));
+    HIP_TRY(c, hipMalloc((void**)&c->d_tris, tb));
+    HIP_TRY(c, hipMemcpy(c->d_nodes, out_nodes.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tris, out_tris.data(), tb, hipMemcpyHostToDevice));
+    c->n_inner = n_out;
+    c->n_refs = n_refs;
+    c->n_leaves = n_leaves;
+    c->max_depth = max_depth;
+    c->scene_bytes = nb + tb;
+    c->has_bvh = true;
+    return PT_OK;
+}
+
+int pt_upload_spheres(pt_ctx* c, const pt_sphere* spheres, size_t n) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    if (n > 0 && !spheres) return fail(c, PT_ERR_INVALID, "pt_upload_spheres: null array");
+    if (n > 4096) return fail(c, PT_ERR_INVALID, "pt_upload_spheres: too many spheres");
+    for (size_t i = 0; i < n; i++)
+        if (spheres[i].mat < PT_MAT_DIFF || spheres[i].mat > PT_MAT_REFR) return fail(c, PT_ERR_INVALID, "pt_upload_spheres: bad material");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_spheres); c->d_spheres = nullptr;
+    c->n_spheres = 0;
+    if (n) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_spheres, n * sizeof(pt_sphere)));
+        HIP_TRY(c, hipMemcpy(c->d_spheres, spheres, n * sizeof(pt_sphere), hipMemcpyHostToDevice));
+        c->n_spheres = (int)n;
+    }
+    return PT_OK;
+}
+
+int pt_scene_info(pt_ctx* c, uint64_t* n_inner, uint64_t* n_refs, uint64_t* n_leaves, uint32_t* max_depth, uint64_t* bytes) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    if (!c->has_bvh) return fail(c, PT_ERR_NO_SCENE, "pt_scene_info: no BVH uploaded");
+    if (n_inner) *n_inner = c->n_inner;
+    if (n_refs) *n_refs = c->n_refs;
+    if (n_leaves) *n_leaves = c->n_leaves;
+    if (max_depth) *max_depth = c->max_depth;
+    if (bytes) *bytes = c->scene_bytes;
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* cam, const pt_params* p, uint32_t spp) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    if (!accum_dev || !cam || !p) return fail(c, PT_ERR_INVALID, "pt_render: null argument");
+    if (p->width < 2 || p->height < 2) return fail(c, PT_ERR_INVALID, "pt_render: image must be at least 2x2 (the camera divides by w-1, h-1)");
+    if (spp == 0) return fail(c, PT_ERR_INVALID, "pt_render: spp must be >= 1");
+    if (p->sample_index == 0) return fail(c, PT_ERR_INVALID, "pt_render: sample_index (constantPdf) starts at 1");
+    if (p->tri_mat < PT_MAT_DIFF || p->tri_mat > PT_MAT_REFR) return fail(c, PT_ERR_INVALID, "pt_render: bad triangle material");
+    if ((p->flags & PT_FLAG_WRITE_RGBA) && !rgba_dev) return fail(c, PT_ERR_INVALID, "pt_render: PT_FLAG_WRITE_RGBA needs rgba_dev");
+    if (!c->has_bvh && c->n_spheres == 0) return fail(c, PT_ERR_NO_SCENE, "pt_render: no scene uploaded");
+    if (p->part_count > 1) {
+        if (p->part_index < 0 || p->part_index >= p->part_count) return fail(c, PT_ERR_INVALID, "pt_render: part_index out of range");
+        if (p->part_rows <= 0 || (p->part_rows % PT_TILE) != 0) return fail(c, PT_ERR_INVALID, "pt_render: part_rows must be a positive multiple of 8");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    KParams P;
+    std::memset(&P, 0, sizeof P);
+    P.sc.nodes = c->d_nodes;
+    P.sc.tris = c->d_tris;
+    P.sc.spheres = c->d_spheres;
+    P.sc.n_spheres = c->n_spheres;
+    P.sc.has_bvh = c->has_bvh ? 1 : 0;
+    P.accum = accum_dev;
+    P.rgba = rgba_dev;
+    P.counters = c->d_counters;
+    P.cam = *cam;
+    P.W = p->width; P.H = p->height;
+    P.depth = p->depth;
+    P.cull = p->cull_backfaces;
+    P.frame = p->frame; P.sample_index = p->sample_index; P.spp = spp;
+    P.tri_mat = p->tri_mat;
+    for (int i = 0; i < 3; i++) { P.tri_col[i] = p->tri_col[i]; P.tri_emi[i] = p->tri_emi[i]; P.bk[i] = p->bk_color[i]; }
+    P.air_ior = p->air_ior; P.glass_ior = p->glass_ior; P.phong = p->phong_expo;
+    P.flags = p->flags;
+    P.tiles_x = (p->width + PT_TILE - 1) / PT_TILE;
+    P.tile_rows = (p->height + PT_TILE - 1) / PT_TILE;
+    if (p->part_count > 1) {
+        P.part_index = p->part_index; P.part_count = p->part_count; P.stripe_tr = p->part_rows / PT_TILE;
+        const int n_stripes = (P.tile_rows + P.stripe_tr - 1) / P.stripe_tr;
+        const int owned = (n_stripes - p->part_index + p->part_count - 1) / p->part_count;  // stripes index, index+count, ...
+        P.n_tiles = owned * P.stripe_tr * P.tiles_x;
+    } else {
+        P.part_index = 0; P.part_count = 1; P.stripe_tr = 1;
+        P.n_tiles = P.tile_rows * P.tiles_x;
+    }
+    if (P.n_tiles <= 0) return PT_OK;
+    const int waves_per_block = PT_BLOCK / 64;
+    const int blocks = (P.n_tiles + waves_per_block - 1) / waves_per_block;
+
+    if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    switch (stack_for_depth(c->has_bvh ? c->max_depth : 0)) {
+        case 24: launch_mega<24>(c, P, blocks); break;
+        case 32: launch_mega<32>(c, P, blocks); break;
+        case 48: launch_mega<48>(c, P, blocks); break;
+        default: launch_mega<72>(c, P, blocks); break;
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
+    return PT_OK;
+}
+
+int pt_trace_rays(pt_ctx* c, const float* rays_dev, size_t n, int cull, float* t_dev, int32_t* tri_dev, float* normal_dev) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    if (!c->has_bvh) return fail(c, PT_ERR_NO_SCENE, "pt_trace_rays: no BVH uploaded");
+    if (n == 0) return PT_OK;
+    if (!rays_dev || !t_dev || !tri_dev) return fail(c, PT_ERR_INVALID, "pt_trace_rays: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    KScene sc;
+    sc.nodes = c->d_nodes; sc.tris = c->d_tris; sc.spheres = nullptr; sc.n_spheres = 0; sc.has_bvh = 1;
+    const int blocks = (int)((n + PT_BLOCK - 1) / PT_BLOCK);
+    if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    const float4* r4 = (const float4*)rays_dev;
+    switch (stack_for_depth(c->max_depth)) {
+        case 24: hipLaunchKernelGGL((k_trace_rays_bvh2<24>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
+        case 32: hipLaunchKernelGGL((k_trace_rays_bvh2<32>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
+        case 48: hipLaunchKernelGGL((k_trace_rays_bvh2<48>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
+        default: hipLaunchKernelGGL((k_trace_rays_bvh2<72>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
+    return PT_OK;
+}
+
+int pt_get_counters(pt_ctx* c, pt_counters* out) {
+    if (!c || !out) return fail(c, PT_ERR_INVALID, "pt_get_counters: null argument");
+    unsigned long long h[8];
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->rays = h[0]; out->inner = h[1]; out->tris = h[2]; out->leaves = h[3]; out->hits = h[4]; out->paths = h[5];
+    return PT_OK;
+}
+
+int pt_last_kernel_ms(pt_ctx* c, float* ms) {
+    if (!c || !ms) return fail(c, PT_ERR_INVALID, "pt_last_kernel_ms: null argument");
+    if (!c->timed) return fail(c, PT_ERR_INVALID, "pt_last_kernel_ms: no timed launch (set PT_OPT_TIMING=1 first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PT_OK;
+}
+
+}  // extern "C"

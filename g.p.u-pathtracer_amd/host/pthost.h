@@ -1,0 +1,86 @@
+/*
+ * pthost.h — host-side scene preparation ("libpthost.so", CPU only, no HIP).
+ *
+ * In a real drop-in the reference's own host code stays (utilfun.cpp loadIndexedTris →
+ * SceneMesh → BVH/SplitBVHBuilder → CudaBVH::createCompact, BasicScene.cpp:281-294) and
+ * hands its three arrays to pt_upload_bvh.  The reference does not travel to the GPU box,
+ * so this library re-creates that producer clean-room: mesh ingest (OBJ v/f records or the
+ * committed .ptmesh fixtures), a SAH BVH builder (binned object splits + optional
+ * Stich-et-al. spatial splits), and a flatten step that emits EXACTLY the reference's
+ * "Compact" layout (GpuPathTracer/CudaBVH.cpp:121-270):
+ *   nodes : 4 x vec4 per inner node  [c0.lo.x c0.hi.x c0.lo.y c0.hi.y]
+ *                                    [c1.lo.x c1.hi.x c1.lo.y c1.hi.y]
+ *                                    [c0.lo.z c0.hi.z c1.lo.z c1.hi.z]
+ *                                    [link0 link1 0 0]   (int bits)
+ *           link >= 0: BYTE offset of the child node; link < 0: ~(index of the leaf's
+ *           first vec4 in the triangle array).  Root at offset 0.
+ *   tris  : per leaf, 3 vec4 (v0,v1,v2 as xyz,0) per triangle reference, then one
+ *           terminator vec4 of 0x80000000 words        (CudaBVH.cpp:184-205)
+ *   index : int array parallel to tris: [triId,0,0] per reference, 0 per terminator
+ *           (CudaBVH.cpp:201-212)
+ * Differences from the reference producer, both fixes of crashes:
+ * a root that is a leaf is wrapped in an inner node whose second child is an empty,
+ * never-hit leaf (CudaBVH.cpp:141 asserts instead), and multi-object OBJ files load
+ * (utilfun.cpp:474 asserts exactly one shape).
+ */
+#ifndef PTHOST_H
+#define PTHOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pth_mesh pth_mesh;
+typedef struct pth_bvh pth_bvh;
+
+typedef struct pth_build_params {
+    int32_t max_leaf_size;   /* Platform::m_maxLeafSize (bvh_util.hpp), default 0x7FFFFFF */
+    int32_t min_leaf_size;   /* Platform::m_minLeafSize, default 1                        */
+    int32_t max_depth;       /* SplitBVHBuilder MaxDepth = 64 (SplitBVHBuilder.hpp:15)     */
+    int32_t n_bins;          /* object-split SAH bins per axis (0 = full sweep)             */
+    float sah_node_cost;     /* Platform::m_SAHNodeCost = 1                                */
+    float sah_tri_cost;      /* Platform::m_SAHTriangleCost = 1                            */
+    float split_alpha;       /* BuildParams::splitAlpha = 1e-5; < 0 disables spatial splits */
+    int32_t n_spatial_bins;  /* SplitBVHBuilder NumSpatialBins = 32                         */
+} pth_build_params;
+
+typedef struct pth_bvh_stats {
+    uint64_t n_inner, n_leaves, n_tri_refs;
+    uint32_t max_depth;      /* edges on the longest root-to-leaf path                      */
+    float sah_cost;
+    double build_ms;
+} pth_bvh_stats;
+
+const char* pth_last_error(void);
+void pth_default_build_params(pth_build_params* p);
+
+/* ---- meshes ---- */
+pth_mesh* pth_mesh_create(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris);
+pth_mesh* pth_mesh_load_obj(const char* path);      /* `v` / `f` records, fan-triangulated  */
+pth_mesh* pth_mesh_load_ptmesh(const char* path);   /* the committed .ptmesh fixtures under assets/ */
+/* append src transformed by the row-major 3x4 affine m (NULL = identity) */
+int pth_mesh_append(pth_mesh* dst, const pth_mesh* src, const float* m3x4);
+size_t pth_mesh_n_verts(const pth_mesh* m);
+size_t pth_mesh_n_tris(const pth_mesh* m);
+const float* pth_mesh_verts(const pth_mesh* m);
+const int32_t* pth_mesh_tris(const pth_mesh* m);
+void pth_mesh_bounds(const pth_mesh* m, float lo[3], float hi[3]);
+void pth_mesh_free(pth_mesh* m);
+
+/* ---- BVH build + flatten to the Compact layout ---- */
+pth_bvh* pth_bvh_build(const pth_mesh* mesh, const pth_build_params* params);
+const float* pth_bvh_nodes(const pth_bvh* b);        size_t pth_bvh_n_node_vec4(const pth_bvh* b);
+const float* pth_bvh_tris(const pth_bvh* b);         size_t pth_bvh_n_tri_vec4(const pth_bvh* b);
+const int32_t* pth_bvh_index(const pth_bvh* b);      size_t pth_bvh_n_index(const pth_bvh* b);
+void pth_bvh_get_stats(const pth_bvh* b, pth_bvh_stats* out);
+void pth_bvh_free(pth_bvh* b);
+
+/* uf::hash (utilfun.cpp:380-389): the per-frame seed the App loop passes down. */
+uint64_t pth_frame_hash(uint64_t frame);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

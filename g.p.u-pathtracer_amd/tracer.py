@@ -1,0 +1,145 @@
+"""PathTracer — Python mirror of the reference's device-facing surface, over the C ABI.
+
+Reference interface mirrored (same names / argument meaning where one exists):
+  BasicScene::launchKernel(const kernelInfo&)   tracer.cu:405-415  → PathTracer.launch_kernel(cam, params, spp)
+  cudaMalloc/cudaMemcpy of the CudaBVH arrays  BasicScene.cpp:297-306 → PathTracer.upload_bvh(bvh)
+  cudaMalloc/cudaMemcpy of the sphere array     BasicScene.cpp:214-215 → PathTracer.upload_spheres(spheres)
+  accumBuffer / dev_drawRes allocation          BasicScene.cpp:138-149 → PathTracer.alloc_frame(w, h)
+Errors: the reference prints and exit(1)s (utilfun.hpp:81-90); here every failure raises
+PtError carrying pt_last_error().  There is no CPU fallback of any kind.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import Camera, Counters, Params, Sphere
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ptmi error {code}: {msg}")
+        self.code = code
+
+
+class DeviceBuffer:
+    """A raw device allocation owned by a PathTracer (pt_malloc / pt_free)."""
+
+    def __init__(self, owner, nbytes):
+        self.owner, self.nbytes = owner, nbytes
+        p = C.c_void_p()
+        owner._check(owner._lib.pt_malloc(owner._ctx, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def zero(self):
+        self.owner._check(self.owner._lib.pt_memset(self.owner._ctx, self.ptr, 0, self.nbytes))
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.owner._check(self.owner._lib.pt_download(self.owner._ctx, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        self.owner._check(self.owner._lib.pt_upload(self.owner._ctx, self.ptr, a.ctypes.data, a.nbytes))
+
+    def free(self):
+        if self.ptr:
+            self.owner._lib.pt_free(self.owner._ctx, self.ptr)
+            self.ptr = None
+
+
+class PathTracer:
+    def __init__(self, device=0):
+        self._lib = _abi.ptmi()
+        ctx = C.c_void_p()
+        rc = self._lib.pt_create(device, C.byref(ctx))
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_last_error(None).decode())
+        self._ctx = ctx
+        self.device = device
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise PtError(rc, self._lib.pt_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.pt_set_stream(self._ctx, hip_stream_ptr))
+
+    def set_option(self, opt, value):
+        self._check(self._lib.pt_set_option(self._ctx, opt, int(value)))
+
+    def sync(self):
+        self._check(self._lib.pt_sync(self._ctx))
+
+    def malloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # ------------------------------------------------------------------ scene
+    def upload_bvh(self, bvh):
+        n, t, i = (np.ascontiguousarray(bvh.nodes, np.float32), np.ascontiguousarray(bvh.tris, np.float32),
+                   np.ascontiguousarray(bvh.index, np.int32))
+        self._check(self._lib.pt_upload_bvh(self._ctx, n.ctypes.data, n.size // 4, t.ctypes.data, t.size // 4,
+                                            i.ctypes.data, i.size))
+
+    def upload_bvh_arrays(self, nodes, n_node_vec4, tris, n_tri_vec4, index, n_index):
+        self._check(self._lib.pt_upload_bvh(self._ctx, nodes, n_node_vec4, tris, n_tri_vec4, index, n_index))
+
+    def upload_spheres(self, spheres):
+        n = len(spheres) if spheres is not None else 0
+        self._check(self._lib.pt_upload_spheres(self._ctx, spheres if n else None, n))
+
+    def scene_info(self):
+        a, b, c_, e = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        d = C.c_uint32()
+        self._check(self._lib.pt_scene_info(self._ctx, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(e)))
+        return {"n_inner": a.value, "n_tri_refs": b.value, "n_leaves": c_.value, "max_depth": d.value,
+                "device_bytes": e.value}
+
+    # ------------------------------------------------------------------ hot path
+    def alloc_frame(self, width, height):
+        """accumBuffer (vec3[W*H], zeroed) and dev_drawRes (uint[W*H]), BasicScene.cpp:138-149."""
+        acc = self.malloc(width * height * 12)
+        acc.zero()
+        rgba = self.malloc(width * height * 4)
+        rgba.zero()
+        return acc, rgba
+
+    def launch_kernel(self, accum_ptr, rgba_ptr, cam, params, spp=1):
+        """render(accum, bvh, camera, spp): asynchronous until sync()."""
+        self._check(self._lib.pt_render(self._ctx, accum_ptr, rgba_ptr, C.byref(cam), C.byref(params), spp))
+
+    def trace_rays(self, rays_ptr, n, cull, t_ptr, tri_ptr, normal_ptr=None):
+        self._check(self._lib.pt_trace_rays(self._ctx, rays_ptr, n, int(cull), t_ptr, tri_ptr, normal_ptr))
+
+    # ------------------------------------------------------------------ measurement
+    def counters(self):
+        c = Counters()
+        self._check(self._lib.pt_get_counters(self._ctx, C.byref(c)))
+        return {f: getattr(c, f) for f, _ in Counters._fields_}
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self._lib.pt_last_kernel_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
+
+def algorithmic_bytes(counters, n_spheres):
+    """B = sum(64*N_inner + 48*N_tri + 16*N_leaf + 4*[hit]) + 44*n_spheres per
+    segment + 28 B per pixel-sample (12 accum read + 12 accum write + 4 RGBA8 write)."""
+    return (64 * counters["inner"] + 48 * counters["tris"] + 16 * counters["leaves"] + 4 * counters["hits"]
+            + 44 * n_spheres * counters["rays"] + 28 * counters["paths"])

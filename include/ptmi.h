@@ -1,0 +1,199 @@
+/*
+ * ptmi.h — C ABI of the MI355X-native progressive path tracer ("libptmi.so").
+ *
+ * This is the drop-in boundary for the ONE host→device call of the reference:
+ *
+ *     void BasicScene::launchKernel(const kernelInfo&)
+ *         declared  GpuPathTracer/BasicScene.hpp:32
+ *         defined   GpuPathTracer/tracer.cu:405-415   (trace<<<grid,16x16>>>(info))
+ *         called    GpuPathTracer/BasicScene.cpp:404   (once per displayed frame)
+ *
+ * plus the device-buffer set-up the reference's constructor performs for that call
+ * (cudaMalloc/cudaMemcpy of the three CudaBVH arrays and the sphere array,
+ * GpuPathTracer/BasicScene.cpp:138-149, :214-215, :297-313).
+ *
+ * Everything crossing the boundary is plain C: fixed-width integers, float arrays,
+ * raw pointers and sizes.  No glm, no bool, no C++ default initialisers (kernelInfo,
+ * GpuPathTracer/CpuStructs.hpp:45-72, is not a C layout), no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative pt_status on failure; nothing
+ *     ever calls exit() (the reference's checkCudaErrors does: utilfun.hpp:81-90);
+ *     pt_last_error(ctx) returns a human-readable message for the last failure.
+ *   - a ctx binds one HIP device and one stream.  Calls on one ctx are not re-entrant;
+ *     different ctxs may be driven from different threads / processes (one per GPU).
+ *   - pt_render is asynchronous with respect to the host until pt_sync.
+ *   - "device pointer" arguments may come from pt_malloc or from any other HIP
+ *     allocator in the same process (hipMalloc, a torch tensor's data_ptr()).
+ */
+#ifndef PTMI_H
+#define PTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_ABI_VERSION 1
+
+typedef struct pt_ctx pt_ctx;
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument (null pointer, zero size, inconsistent arrays) */
+    PT_ERR_DEVICE = -2,    /* a HIP call failed (message has hipGetErrorString)           */
+    PT_ERR_NO_SCENE = -3,  /* pt_render / pt_trace_rays before pt_upload_bvh              */
+    PT_ERR_NOMEM = -4,
+    PT_ERR_UNSUPPORTED = -5
+} pt_status;
+
+/* Mat, GpuPathTracer/CommomStructs.hpp:12 — same numeric values. */
+enum { PT_MAT_DIFF = 0, PT_MAT_METAL = 1, PT_MAT_SPEC = 2, PT_MAT_REFR = 3 };
+
+/* pt_params.flags */
+enum {
+    /* METAL lobe adds float(image width)*cos(theta) to every component, exactly as
+     * tracer.cu:280 does (`w` there is the int image width from tracer.cu:45).
+     * Default (flag clear) is the intended  w1*cos(theta)  (SURVEY.md §3.4 table). */
+    PT_FLAG_METAL_LITERAL_W = 1u << 0,
+    /* also write the 0x00BBGGRR display word (tracer.cu:394-398); needs rgba_dev. */
+    PT_FLAG_WRITE_RGBA = 1u << 1
+};
+
+/* pt_ctx kernel selection (pt_set_option PT_OPT_KERNEL) */
+enum {
+    PT_KERNEL_AUTO = 0,      /* best validated variant for the uploaded scene           */
+    PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, binary tree, bit-exact vs oracle    */
+    PT_KERNEL_MEGA_WIDE = 2, /* one lane per pixel, 4-wide 128-byte nodes                */
+    PT_KERNEL_PERSISTENT = 3,/* persistent waves, tile queue, lane refill               */
+    PT_KERNEL_WAVEFRONT = 4  /* stage-split: generate / extend / shade with compaction   */
+};
+
+enum {
+    PT_OPT_KERNEL = 1,        /* one of PT_KERNEL_*                                        */
+    PT_OPT_COUNTERS = 2,      /* 1 = instrumented launch: fill pt_counters (slower)         */
+    PT_OPT_TIMING = 3         /* 1 = bracket every launch with hipEvents (pt_last_kernel_ms) */
+};
+
+/* CamInfo, GpuPathTracer/CpuStructs.hpp:19-28 (pitch/yaw/dirty/bias/enabled are host-only
+ * GUI state and never read by the kernel: cudaUtils.h:111-134). */
+typedef struct pt_camera {
+    float pos[3];
+    float front[3];
+    float right[3];
+    float up[3];
+    float dist;
+    float aspect;
+    float fov;
+    float _pad;
+} pt_camera;
+
+/* Sphere, GpuPathTracer/CommomStructs.hpp:18-39 — 44 bytes, same field order. */
+typedef struct pt_sphere {
+    float pos_rad[4];  /* centre xyz, radius */
+    float emi[3];
+    float col[3];
+    int32_t mat;       /* PT_MAT_* */
+} pt_sphere;
+
+/* The scalar part of kernelInfo (GpuPathTracer/CpuStructs.hpp:45-72) that the kernel
+ * reads (tracer.cu:27-400); pointer members travel as explicit arguments. */
+typedef struct pt_params {
+    int32_t width, height;        /* kernelInfo::width/height                              */
+    uint32_t depth;               /* kernelInfo::depth          (tracer.cu:72)             */
+    int32_t cull_backfaces;       /* kernelInfo::cullBackFaces  (cudaUtils.h:151-155)      */
+    uint64_t frame;               /* frameNumber; the kernel seed is uf::hash(frame)
+                                     (BasicScene.cpp:397, utilfun.cpp:380-389)             */
+    uint64_t sample_index;        /* kernelInfo::constantPdf = N of the running mean for
+                                     the first sample of this call; 1 = overwrite
+                                     (BasicScene.cpp:399, tracer.cu:386-391)               */
+    int32_t tri_mat;              /* kernelInfo::triCurrentMat  (tracer.cu:135)            */
+    float tri_col[3];             /* kernelInfo::col            (tracer.cu:131)            */
+    float tri_emi[3];             /* kernelInfo::emi            (tracer.cu:132)            */
+    float bk_color[3];            /* kernelInfo::bkColor        (tracer.cu:141)            */
+    float air_ior;                /* kernelInfo::air_ref_index                              */
+    float glass_ior;              /* kernelInfo::glass_ref_index                            */
+    float phong_expo;             /* kernelInfo::phongExpo                                  */
+    uint32_t flags;               /* PT_FLAG_*                                              */
+    /* Framebuffer partition for multi-GPU tile split (new; the reference is single-GPU).
+     * The image is cut into stripes of `part_rows` rows; this call renders only stripes
+     * s with  s % part_count == part_index.  part_count <= 1 renders everything.
+     * RNG is keyed by the GLOBAL pixel index, so any partition gives bit-identical
+     * pixels.  accum/rgba are always full-frame buffers. */
+    int32_t part_index, part_count, part_rows;
+    int32_t _pad;
+} pt_params;
+
+/* Work counters of the last instrumented launch (PT_OPT_COUNTERS=1).  They are the
+ * N_* of the algorithmic-byte definition in SURVEY.md §8(d). */
+typedef struct pt_counters {
+    uint64_t rays;        /* closest-hit queries (ray segments)          */
+    uint64_t inner;       /* inner nodes fetched                          */
+    uint64_t tris;        /* triangle records tested                      */
+    uint64_t leaves;      /* leaves entered                               */
+    uint64_t hits;        /* segments that ended on a triangle            */
+    uint64_t paths;       /* pixel-samples                                */
+} pt_counters;
+
+/* ---- context ------------------------------------------------------------------ */
+int pt_abi_version(void);
+int pt_device_count(void);                       /* <0 on error                     */
+int pt_create(int device, pt_ctx** out);
+int pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(const pt_ctx* ctx);     /* ctx may be NULL: global message  */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream); /* NULL = ctx's own stream          */
+int pt_set_option(pt_ctx* ctx, int option, int value);
+int pt_sync(pt_ctx* ctx);
+
+/* ---- memory (thin; callers may also pass pointers from their own allocator) ----- */
+int pt_malloc(pt_ctx* ctx, size_t bytes, void** dev_out);
+int pt_free(pt_ctx* ctx, void* dev);
+int pt_memset(pt_ctx* ctx, void* dev, int value, size_t bytes);
+int pt_download(pt_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+int pt_upload(pt_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+
+/* ---- scene -------------------------------------------------------------------
+ * pt_upload_bvh consumes the three host arrays CudaBVH::createCompact produces
+ * (GpuPathTracer/CudaBVH.cpp:121-270) — exactly what BasicScene.cpp:297-306 copies:
+ *   nodes      getGpuNodes()/getGpuNodesSize():  vec4[n_node_vec4], 4 per inner node,
+ *              child link >=0 = BYTE offset of the child node, <0 = ~(first tri vec4)
+ *   tri_verts  getDebugTri()/getDebugTriSize():  vec4[n_tri_vec4], per leaf
+ *              {v0,v1,v2 (xyz,0)}*k followed by one 0x80000000 terminator vec4
+ *   tri_index  getGpuTriIndices():               int[n_index], parallel to tri_verts
+ * The arrays are validated, copied and re-laid-out for gfx950; the host
+ * arrays may be freed when the call returns. */
+int pt_upload_bvh(pt_ctx* ctx,
+                  const float* nodes, size_t n_node_vec4,
+                  const float* tri_verts, size_t n_tri_vec4,
+                  const int32_t* tri_index, size_t n_index);
+int pt_upload_spheres(pt_ctx* ctx, const pt_sphere* spheres, size_t n_spheres);
+
+/* ---- the hot path -------------------------------------------------------------
+ * render(accum, bvh, camera, spp) of BASELINE.json: fold `spp` consecutive samples
+ * (frames params->frame .. frame+spp-1, running-mean N = sample_index .. +spp-1) into
+ * accum_dev (float[height][width][3], the reference's vec3 accumBuffer) and, when
+ * PT_FLAG_WRITE_RGBA is set, the display word into rgba_dev (uint32[height][width],
+ * the reference's dev_drawRes).  Equals `spp` single-sample calls bit for bit. */
+int pt_render(pt_ctx* ctx, float* accum_dev, uint32_t* rgba_dev,
+              const pt_camera* cam, const pt_params* params, uint32_t spp);
+
+/* Closest-hit query on an explicit ray batch (rows a5–a7 of SURVEY.md §8 in isolation,
+ * = intersectBVHandTriangles, cudaUtils.h:256-460).  rays_dev: float[n][8] =
+ * (ox,oy,oz,tmin=0, dx,dy,dz,unused); out t_dev float[n] (F32_MAX on miss),
+ * tri_dev int32[n] (original triangle id, -1 on miss), normal_dev float[n][3]
+ * (un-normalised cross(v0-v1, v0-v2) of the winner; may be NULL). */
+int pt_trace_rays(pt_ctx* ctx, const float* rays_dev, size_t n_rays, int cull_backfaces,
+                  float* t_dev, int32_t* tri_dev, float* normal_dev);
+
+/* ---- measurement --------------------------------------------------------------- */
+int pt_get_counters(pt_ctx* ctx, pt_counters* out);
+int pt_last_kernel_ms(pt_ctx* ctx, float* ms_out);   /* needs PT_OPT_TIMING=1 */
+int pt_scene_info(pt_ctx* ctx, uint64_t* n_inner, uint64_t* n_tri_refs,
+                  uint64_t* n_leaves, uint32_t* max_depth, uint64_t* device_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H */
