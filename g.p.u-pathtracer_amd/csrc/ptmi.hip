@@ -16,6 +16,7 @@
 
 static_assert(sizeof(pt_sphere) == 44, "pt_sphere must match the reference Sphere (44 B)");
 static_assert(sizeof(pt_sphere_d) == sizeof(pt_sphere), "device sphere mirror");
+static_assert(sizeof(pt_params) == 104 && sizeof(pt_camera) == 64 && sizeof(pt_counters) == 48, "ABI struct sizes (tests/test_host_and_abi.py)");
 
 namespace {
 thread_local std::string g_err;

@@ -1,0 +1,143 @@
+// pt_app.cpp — headless "App render loop": what BasicScene::run() (GpuPathTracer/
+// BasicScene.cpp:368-477) does per frame, minus window/GL/ImGui, over the C ABI.
+//
+//   per frame:  sync (BasicScene.cpp:395) → frame seed (:397) → constantPdf logic (:399)
+//               → launchKernel (:404) → [display copy :424-432 → here: optional download]
+//
+// Usage: pt_app --mesh assets/cornell.ptmesh [--width 1280 --height 720 --frames 16
+//               --depth 4 --mat 0..3 --no-spheres --device 0 --out image.ppm]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptmi.h"
+#include "pthost.h"
+
+static int die(const char* what, const char* msg) {
+    std::fprintf(stderr, "pt_app: %s: %s\n", what, msg ? msg : "");
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    std::string mesh_path, out_path;
+    int W = 1280, H = 720, frames = 16, depth = 4, mat = PT_MAT_DIFF, device = 0;
+    bool spheres = true;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", name); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--mesh") mesh_path = next("--mesh");
+        else if (a == "--out") out_path = next("--out");
+        else if (a == "--width") W = std::atoi(next("--width"));
+        else if (a == "--height") H = std::atoi(next("--height"));
+        else if (a == "--frames") frames = std::atoi(next("--frames"));
+        else if (a == "--depth") depth = std::atoi(next("--depth"));
+        else if (a == "--mat") mat = std::atoi(next("--mat"));
+        else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--no-spheres") spheres = false;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (mesh_path.empty()) return die("usage", "--mesh <file.obj|file.ptmesh> is required");
+
+    const bool is_ptmesh = mesh_path.size() > 7 && mesh_path.substr(mesh_path.size() - 7) == ".ptmesh";
+    pth_mesh* mesh = is_ptmesh ? pth_mesh_load_ptmesh(mesh_path.c_str()) : pth_mesh_load_obj(mesh_path.c_str());
+    if (!mesh) return die("mesh", pth_last_error());
+    pth_bvh* bvh = pth_bvh_build(mesh, nullptr);
+    if (!bvh) return die("bvh", pth_last_error());
+    pth_bvh_stats st;
+    pth_bvh_get_stats(bvh, &st);
+    std::printf("mesh %zu tris; bvh %llu inner, %llu leaves, depth %u, built in %.1f ms\n", pth_mesh_n_tris(mesh),
+                (unsigned long long)st.n_inner, (unsigned long long)st.n_leaves, st.max_depth, st.build_ms);
+
+    pt_ctx* ctx = nullptr;
+    if (pt_create(device, &ctx) != PT_OK) return die("pt_create", pt_last_error(nullptr));
+    if (pt_upload_bvh(ctx, pth_bvh_nodes(bvh), pth_bvh_n_node_vec4(bvh), pth_bvh_tris(bvh), pth_bvh_n_tri_vec4(bvh),
+                      pth_bvh_index(bvh), pth_bvh_n_index(bvh)) != PT_OK)
+        return die("pt_upload_bvh", pt_last_error(ctx));
+
+    // the reference's sphere room, BasicScene.cpp:181-202
+    std::vector<pt_sphere> sph;
+    if (spheres) {
+        const float rad = 600.f, px = 20.f, py = 15.f;
+        const float a[3] = {197.f / 255.f, 153.f / 255.f, 92.f / 255.f};
+        auto add = [&](float x, float y, float z, float r, const float* e, float cr, float cg, float cb, int m) {
+            pt_sphere s{{x, y, z, r}, {e[0], e[1], e[2]}, {cr, cg, cb}, m};
+            sph.push_back(s);
+        };
+        const float red[3] = {165.f / 255.f, 15.f / 255.f, 0.f}, green[3] = {30.f / 255.f, 76.f / 255.f, 14.f / 255.f};
+        const float cyan[3] = {0.f, 1.f, 0.8f}, zero[3] = {0, 0, 0}, lamp[3] = {0.f, 1.f, 1.f};
+        add(0, -py - rad, -20, rad, a, .5f, .5f, .5f, PT_MAT_DIFF);
+        add(0, py + rad, -20, rad, a, .1f, .3f, .4f, PT_MAT_DIFF);
+        add(px + rad, 0, -20, rad, red, red[0], red[1], red[2], PT_MAT_DIFF);
+        add(-px - rad, 0, -20, rad, green, green[0], green[1], green[2], PT_MAT_DIFF);
+        add(0, 0, -rad * 1.5f - 20, rad, a, 1, 1, 1, PT_MAT_DIFF);
+        add(0, 0, rad * 1.5f + 20, rad, cyan, .5f, .5f, .5f, PT_MAT_DIFF);
+        add(13, -8, -35, 6, zero, 1, 1, 1, PT_MAT_SPEC);
+        add(10, -15, -68, 10, lamp, 1, 1, 1, PT_MAT_DIFF);
+        if (pt_upload_spheres(ctx, sph.data(), sph.size()) != PT_OK) return die("pt_upload_spheres", pt_last_error(ctx));
+    }
+
+    // kernel defaults (BasicScene.cpp:220-236) and camera (:239-259)
+    pt_camera cam{};
+    cam.front[2] = -1.f; cam.right[0] = 1.f; cam.up[1] = 1.f;
+    cam.dist = (float)(H / 60);
+    cam.aspect = W * 1.0f / H;
+    cam.fov = 1.0f;
+    pt_params p{};
+    p.width = W; p.height = H; p.depth = (uint32_t)depth; p.cull_backfaces = 1;
+    p.tri_mat = mat;
+    p.tri_col[0] = 246.f / 256.f; p.tri_col[1] = 246.f / 255.f; p.tri_col[2] = 70.f / 255.f;
+    p.bk_color[0] = p.bk_color[1] = p.bk_color[2] = 1.f;
+    p.air_ior = 1.0f; p.glass_ior = 1.4f; p.phong_expo = 30.f;
+    p.flags = PT_FLAG_WRITE_RGBA;
+    p.part_count = 1; p.part_rows = 8;
+
+    void *accum = nullptr, *rgba = nullptr;
+    if (pt_malloc(ctx, (size_t)W * H * 12, &accum) != PT_OK || pt_malloc(ctx, (size_t)W * H * 4, &rgba) != PT_OK)
+        return die("pt_malloc", pt_last_error(ctx));
+    pt_memset(ctx, accum, 0, (size_t)W * H * 12);
+
+    uint64_t constantPdf = 0;
+    bool cam_dirty = true;  // first frame overwrites (BasicScene.cpp:399)
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t frameNumber = 0; frameNumber < (uint64_t)frames; ++frameNumber) {
+        if (pt_sync(ctx) != PT_OK) return die("pt_sync", pt_last_error(ctx));       // :395
+        p.frame = frameNumber;                                                      // :397
+        constantPdf = cam_dirty ? 1 : constantPdf + 1;                              // :399
+        cam_dirty = false;
+        p.sample_index = constantPdf;
+        if (pt_render(ctx, (float*)accum, (uint32_t*)rgba, &cam, &p, 1) != PT_OK)   // :404
+            return die("pt_render", pt_last_error(ctx));
+    }
+    pt_sync(ctx);
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double rays = (double)W * H * depth * frames;
+    std::printf("%d frames %dx%d depth %d: %.2f ms/frame, <= %.1f Mrays/s (closed scene bound)\n", frames, W, H, depth,
+                ms / frames, rays / ms / 1e3);
+
+    if (!out_path.empty()) {
+        std::vector<uint32_t> img((size_t)W * H);
+        if (pt_download(ctx, img.data(), rgba, img.size() * 4) != PT_OK) return die("pt_download", pt_last_error(ctx));
+        FILE* f = std::fopen(out_path.c_str(), "wb");
+        if (!f) return die("open", out_path.c_str());
+        std::fprintf(f, "P6\n%d %d\n255\n", W, H);
+        for (int y = H - 1; y >= 0; y--)
+            for (int x = 0; x < W; x++) {
+                uint32_t w = img[(size_t)y * W + x];
+                unsigned char rgb[3] = {(unsigned char)(w & 255), (unsigned char)((w >> 8) & 255), (unsigned char)((w >> 16) & 255)};
+                std::fwrite(rgb, 1, 3, f);
+            }
+        std::fclose(f);
+    }
+    pt_free(ctx, accum);
+    pt_free(ctx, rgba);
+    pt_destroy(ctx);
+    pth_bvh_free(bvh);
+    pth_mesh_free(mesh);
+    return 0;
+}

@@ -370,7 +370,11 @@ int32_t emit_leaf(FlattenCtx& c, const std::vector<int>& ids) {
     for (int id : ids) {
         for (int k = 0; k < 3; k++) {
             const float* v = &c.mesh.verts[3 * (size_t)c.mesh.tris[3 * (size_t)id + k]];
-            c.tris.insert(c.tris.end(), {v[0], v[1], v[2], 0.f});
+            // a v0.x of -0.0f has the terminator's bit pattern (0x80000000) and would end the
+            // leaf early in any consumer of this layout (cudaUtils.h:413); the reference guards
+            // only its Woop rows against it (CudaBVH.cpp:191).  Store +0.0f instead.
+            const float x = (k == 0 && v[0] == 0.f) ? 0.f : v[0];
+            c.tris.insert(c.tris.end(), {x, v[1], v[2], 0.f});
         }
         c.index.insert(c.index.end(), {id, 0, 0});
     }
