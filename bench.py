@@ -69,7 +69,7 @@ def cpu_baseline(g, bvh, sph, cam, params, first_frame, n_frames, spp):
     t0 = time.perf_counter()
     _, _, cnt = orc.render(bvh, sph, cam, p, spp=n_frames * spp, accum=acc, want_rgba=False)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
     return {"value": cnt["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{n_frames} frame(s) x {spp} spp of the bench workload ({p.width}x{p.height}, depth {p.depth}), "
                       f"{cnt['rays']} ray segments in {dt:.2f} s, oracle/pt_oracle.c with OpenMP"}, cnt, acc
@@ -142,7 +142,12 @@ def main():
     base.part_index, base.part_count, base.part_rows = rank, world, a.stripe_rows
 
     pt = g.PathTracer(local_rank)
-    pt.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit HIP stream shared by torch (events, copies, RCCL ordering) and the kernels:
+    # torch.cuda.Event only sees torch's current stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    pt.set_stream(stream.cuda_stream)
     if a.kernel:
         pt.set_option(g.OPT_KERNEL, a.kernel)
     pt.upload_bvh(bvh)
