@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--mat", default="diff", choices=["diff", "metal", "spec", "refr"])
     ap.add_argument("--no-spheres", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="PT_KERNEL_* (0 = auto)")
+    ap.add_argument("--occ", type=int, default=0, help="PT_OPT_OCCUPANCY (0 = library default)")
+    ap.add_argument("--lds-stack", type=int, default=-1, help="PT_OPT_LDS_STACK (-1 = library default)")
+    ap.add_argument("--top", type=int, default=-1, help="PT_OPT_TOP_NODES (-1 = library default)")
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-reference", action="store_true")
@@ -150,6 +153,12 @@ def main():
     pt.set_stream(stream.cuda_stream)
     if a.kernel:
         pt.set_option(g.OPT_KERNEL, a.kernel)
+    if a.occ:
+        pt.set_option(g.OPT_OCCUPANCY, a.occ)
+    if a.lds_stack >= 0:
+        pt.set_option(g.OPT_LDS_STACK, a.lds_stack)
+    if a.top >= 0:
+        pt.set_option(g.OPT_TOP_NODES, a.top)
     pt.upload_bvh(bvh)
     pt.upload_spheres(sph)
     info = pt.scene_info()

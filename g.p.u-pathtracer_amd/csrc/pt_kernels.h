@@ -9,8 +9,11 @@
 #include "pt_math.h"
 #include "../../include/ptmi.h"
 
-#define PT_BLOCK 256          // 4 waves; one wave = one 8x8 pixel tile
+#define PT_BLOCK 256          // frame kernels: 4 waves; one wave = one 8x8 pixel tile
+#define PT_BLOCK_RAYS 256     // ray-batch kernel
 #define PT_TILE 8
+#define PT_MAX_TOP 1024       // most nodes the LDS copy of the top of the tree may hold
+#define PT_STACK_CAP 72       // deepest traversal stack (tree depth <= 64, SplitBVHBuilder MaxDepth)
 
 struct KScene {
     const float4* __restrict__ nodes;   // 4 float4 per inner node, links = float4 indices
@@ -18,6 +21,8 @@ struct KScene {
     const pt_sphere_d* __restrict__ spheres;
     int n_spheres;
     int has_bvh;
+    int n_top;     // nodes [0, n_top) (breadth-first prefix of the tree) are mirrored in LDS
+    int stack_n;   // LDS stack entries per lane
 };
 
 struct KParams {
@@ -39,6 +44,10 @@ struct KParams {
     // from the tile-rows this partition owns (stripes of stripe_tr tile-rows, round-robin)
     int tiles_x, tile_rows, n_tiles;
     int part_index, part_count, stripe_tr;
+    // persistent kernel: global work counter over the n_tiles*64 tile-ordered pixel slots,
+    // and the number of waiting lanes that makes a wave leave the traversal loop
+    unsigned int* queue;
+    int batch;
 };
 
 struct Hit {
@@ -53,32 +62,102 @@ struct TravCount {
 
 // ---------------------------------------------------------------------------------------
 // Binary-tree closest hit, same visiting order and arithmetic as cudaUtils.h:256-460 /
-// oracle/pt_oracle.c:bvh_intersect, so results are bit-identical to the oracle.
+// the CPU restatement, so results are bit-identical to it.
 //   - stack lives in LDS, laid out [entry][thread] → conflict-free for any mix of depths
 //   - slab tests: 12 v_fma + v_min3/v_max3 (the reference's PTX vmin/vmax trick is only
 //     valid for non-negative floats)
 //   - postponed-leaf exit on a 64-lane ballot (cudaUtils.h:383-394 is a 32-lane vote)
-template <bool COUNT>
-__device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull, int* __restrict__ stk,
-                                         TravCount& tc) {
-    const float ooeps = 8.271806125530277e-25f;  // exp2f(-80), cudaUtils.h:283
-    const float idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
-    const float idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
-    const float idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
-    const float oodx = o.x * idx, oody = o.y * idy, oodz = o.z * idz;
+// The walk is resumable: all of its state is in TravState, and run<DYN=true> returns early
+// when enough other lanes of the wave are waiting to be shaded / refilled (persistent
+// kernel); the per-ray sequence of tests is the same either way.
+//   - TOP: the first n_top nodes in breadth-first order (the levels every ray walks) are read
+//     from an LDS mirror laid out as four float4 planes.  rocprof showed the CU's vector
+//     memory pipe (TA/TD) ~90 % busy with 64-byte gathers and 70-80 % of node visits landing
+//     in the top few hundred nodes; ds_read_b128 runs on the LDS pipe instead.
+// Dynamic LDS of the kernels: [top-of-tree planes: 4 x n_top float4][stack: LSTK x BLOCK int].
+// One extern array so the carve base stays 16-byte aligned (cdna guide G17).
+extern __shared__ float4 s_dyn[];
 
-    int sp = 0;
-    stk[0] = PT_SENTINEL;
-    int leaf = 0, node = 0;
+struct TravState {
+    float idx, idy, idz, oodx, oody, oodz;
+    int node, leaf, sp;
     Hit h;
-    h.t = PT_F32_MAX; h.tri = -1; h.n = V3(0.f, 0.f, 0.f);
+};
 
+// Traversal stack: the first LSTK entries of every lane live in LDS ([entry][thread], so any
+// mix of depths is conflict-free); deeper entries — rare: the walk pushes one entry per level
+// that has both children hit — overflow into a private (scratch) array.  A small LSTK is what
+// lets 6-8 waves per SIMD fit in the CU's 160 KiB of LDS (64 B/lane at LSTK = 16).
+template <int LSTK, int BLOCK>
+struct TravStack {
+    int base;  // int index of this lane's entry 0 inside s_dyn (the __shared__ symbol is named in
+               // the accessors so that the loads stay ds_read/ds_write: a stored pointer makes
+               // hipcc merge the LDS and overflow paths into flat_load/flat_store)
+    int ovf[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
+    __device__ __forceinline__ void put(int sp, int v) {
+        if (LSTK >= PT_STACK_CAP || sp < LSTK) {
+            ((int*)s_dyn)[base + sp * BLOCK] = v;
+        } else {
+            asm volatile("" : "+v"(v));
+            ovf[sp - LSTK] = v;
+        }
+    }
+    __device__ __forceinline__ int get(int sp) const {
+        int v;
+        if (LSTK >= PT_STACK_CAP || sp < LSTK) {
+            v = ((const int*)s_dyn)[base + sp * BLOCK];
+        } else {
+            v = ovf[sp - LSTK];
+            asm volatile("" : "+v"(v));
+        }
+        return v;
+    }
+};
+
+template <class STK>
+__device__ __forceinline__ void trav_begin(TravState& s, v3 o, v3 d, STK& stk) {
+    const float ooeps = 8.271806125530277e-25f;  // exp2f(-80), cudaUtils.h:283
+    s.idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+    s.idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+    s.idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+    s.oodx = o.x * s.idx; s.oody = o.y * s.idy; s.oodz = o.z * s.idz;
+    s.sp = 0;
+    stk.put(0, PT_SENTINEL);
+    s.leaf = 0; s.node = 0;
+    s.h.t = PT_F32_MAX; s.h.tri = -1; s.h.n = V3(0.f, 0.f, 0.f);
+}
+
+// returns true when the walk is complete
+template <bool COUNT, bool DYN, bool TOP, class STK>
+__device__ __forceinline__ bool trav_run(TravState& s, const KScene& sc, v3 o, v3 d, bool cull,
+                                         STK& stk, TravCount& tc, int n_dead, int batch,
+                                         const float4* __restrict__ s_top) {
+    int node = s.node, leaf = s.leaf, sp = s.sp;
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
     while (node != PT_SENTINEL) {
         while ((unsigned)node < (unsigned)PT_SENTINEL) {  // node >= 0 && node != sentinel
-            const float4 n0 = sc.nodes[node + 0];
-            const float4 n1 = sc.nodes[node + 1];
-            const float4 nz = sc.nodes[node + 2];
-            const float4 nl = sc.nodes[node + 3];
+            float4 n0, n1, nz, nl;
+            if (TOP && node < sc.n_top * 4) {
+                // read through the __shared__ symbol itself and keep this a real branch: given
+                // a pointer parameter, hipcc if-converts the two paths into ONE generic-pointer
+                // select and emits eleven scalarised flat_load_dword per node
+                const int i = node >> 2;
+                n0 = s_dyn[i];
+                n1 = s_dyn[sc.n_top + i];
+                nz = s_dyn[2 * sc.n_top + i];
+                nl = s_dyn[3 * sc.n_top + i];
+                asm volatile("" : "+v"(n0.x), "+v"(nl.x));
+            } else {
+                n0 = sc.nodes[node + 0];
+                n1 = sc.nodes[node + 1];
+                nz = sc.nodes[node + 2];
+                nl = sc.nodes[node + 3];
+            }
+            int cx = __float_as_int(nl.x), cy = __float_as_int(nl.y);
+            // keep the link load with the three box loads: left alone, hipcc sinks it into the
+            // "hit" branch below, which makes every node visit two dependent round trips
+            asm volatile("" : "+v"(cx), "+v"(cy));
             if (COUNT) tc.inner++;
             const float c0lox = fmaf(n0.x, idx, -oodx), c0hix = fmaf(n0.y, idx, -oodx);
             const float c0loy = fmaf(n0.z, idy, -oody), c0hiy = fmaf(n0.w, idy, -oody);
@@ -93,20 +172,19 @@ __device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull
             const bool t0 = (c0min <= c0max) && (c0min >= 0.0f) && (c0min <= PT_F32_MAX);
             const bool t1 = (c1min <= c1max) && (c1min >= 0.0f) && (c1min <= PT_F32_MAX);
             if (!t0 && !t1) {
-                node = stk[sp * PT_BLOCK];
+                node = stk.get(sp);
                 sp--;
             } else {
-                int cx = __float_as_int(nl.x), cy = __float_as_int(nl.y);
                 node = t0 ? cx : cy;
                 if (t0 && t1) {
                     if (c1min < c0min) { int tmp = node; node = cy; cy = tmp; }
                     sp++;
-                    stk[sp * PT_BLOCK] = cy;
+                    stk.put(sp, cy);
                 }
             }
             if (node < 0 && leaf >= 0) {  // first leaf: postpone, keep descending
                 leaf = node;
-                node = stk[sp * PT_BLOCK];
+                node = stk.get(sp);
                 sp--;
             }
             if (!__ballot(leaf >= 0)) break;  // every active lane holds a leaf
@@ -124,28 +202,55 @@ __device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull
                 if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                     h.t = t;
                     h.tri = id;
-                    // cross(v0-v1, v0-v2) == cross(e1, e2) exactly: v0-v1 = -(v1-v0) bit for bit
+                    // cross(v0-v1, v0-v2): v0-v1 = 0-(v1-v0) bit for bit (incl. the sign of zeros)
                     h.n = vcross(vsub(V3(0.f, 0.f, 0.f), e1), vsub(V3(0.f, 0.f, 0.f), e2));
                 }
                 if (__float_as_int(r1.w) != 0) break;  // last record of the leaf
             }
             leaf = node;
             if (node < 0) {
-                node = stk[sp * PT_BLOCK];
+                node = stk.get(sp);
                 sp--;
             }
         }
+        if (DYN) {  // enough lanes are waiting for service: hand the wave back
+            const int active = __popcll(__ballot(1));
+            if (64 - active - n_dead >= batch) break;
+        }
     }
-    return h;
+    s.node = node; s.leaf = leaf; s.sp = sp; s.h = h;
+    return node == PT_SENTINEL;
+}
+
+template <bool COUNT, bool TOP, class STK>
+__device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                         TravCount& tc, const float4* __restrict__ s_top) {
+    TravState s;
+    trav_begin(s, o, d, stk);
+    trav_run<COUNT, false, TOP, STK>(s, sc, o, d, cull, stk, tc, 0, 0, s_top);
+    return s.h;
+}
+
+
+template <int BLOCK>
+__device__ __forceinline__ void lds_load_top(const KScene& sc, float4* __restrict__ s_top) {
+    for (int i = threadIdx.x; i < sc.n_top * 4; i += BLOCK) s_top[(i & 3) * sc.n_top + (i >> 2)] = sc.nodes[i];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
-// One sample of one pixel: getSample, tracer.cu:27-339.
-template <bool COUNT>
-__device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, pt_rng& rng, int* __restrict__ stk,
-                                            TravCount& tc, uint32_t& n_rays, uint32_t& n_hits) {
-    // getCamRayDir, cudaUtils.h:111-134 (ray origin is ON the image plane)
-    const float u0 = pt_rng_next(rng), u1 = pt_rng_next(rng);
+// One sample of one pixel: getSample, tracer.cu:27-339, cut into the pieces both kernels
+// share: path_begin (camera ray), trav_* (closest hit), path_shade (spheres, shading, BRDF).
+struct PathState {
+    v3 o, d, mask, accu;
+    uint32_t depth;
+    pt_rng rng;
+};
+
+// RNG seed (tracer.cu:362-363) + getCamRayDir, cudaUtils.h:111-134 (origin ON the image plane)
+__device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uint64_t pix, uint64_t frame, PathState& ps) {
+    ps.rng = pt_rng_init(pt_wang64(frame), pix);
+    const float u0 = pt_rng_next(ps.rng), u1 = pt_rng_next(ps.rng);
     const float jx = u0 - 0.5f, jy = u1 - 0.5f;
     const float xs = ((((float)px - (float)P.W / 2.0f) + 0.5f) + jx) * P.cam.dist * P.cam.aspect * P.cam.fov / (float)(P.W - 1);
     const float ys = ((((float)py - (float)P.H / 2.0f) + 0.5f) + jy) * P.cam.dist * P.cam.fov / (float)(P.H - 1);
@@ -153,118 +258,161 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, pt
     const v3 right = V3(P.cam.right[0], P.cam.right[1], P.cam.right[2]);
     const v3 up = V3(P.cam.up[0], P.cam.up[1], P.cam.up[2]);
     const v3 dir0 = vmadd(up, ys, vmadd(right, xs, vscale(front, P.cam.dist)));
-    v3 o = vadd(V3(P.cam.pos[0], P.cam.pos[1], P.cam.pos[2]), dir0);
-    v3 d = vnormalize(dir0);
+    ps.o = vadd(V3(P.cam.pos[0], P.cam.pos[1], P.cam.pos[2]), dir0);
+    ps.d = vnormalize(dir0);
+    ps.mask = V3(1.f, 1.f, 1.f);
+    ps.accu = V3(0.f, 0.f, 0.f);
+    ps.depth = 0;
+}
 
-    v3 mask = V3(1.f, 1.f, 1.f), accu = V3(0.f, 0.f, 0.f);
+// One bounce after the closest triangle hit `h` is known (tracer.cu:98-296).  Returns true
+// when the sample is complete (col_out valid), false when ps holds the next ray segment.
+__device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out) {
+    const v3 o = ps.o, d = ps.d;
+    v3 mask = ps.mask, accu = ps.accu;
+    pt_rng rng = ps.rng;
+    {
+    int geom = 3;  // GeoType::NONE
+    int sph_id = -1;
+    float scene_t = h.t;
+    if (h.tri != -1) geom = 0;
+    // intersectAllSpeheres, cudaUtils.h:221-236 (uniform loop, scalar loads)
+    for (int i = 0; i < P.sc.n_spheres; i++) {
+        const pt_sphere_d& s = P.sc.spheres[i];
+        const float ts = pt_sphere_intersect(s.px, s.py, s.pz, s.rad, o, d);
+        if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
+    }
+    v3 hitpos = vmadd(d, scene_t, o);
+    v3 n, nl, objcol, emit;
+    int mat;
+    if (geom == 1) {
+        const pt_sphere_d& s = P.sc.spheres[sph_id];
+        n = vnormalize(vsub(hitpos, V3(s.px, s.py, s.pz)));
+        nl = vdot(n, d) < 0 ? n : vscale(n, -1.0f);
+        objcol = V3(s.col[0], s.col[1], s.col[2]);
+        emit = V3(s.emi[0], s.emi[1], s.emi[2]);
+        mat = s.mat;
+    } else if (geom == 0) {
+        n = vnormalize(h.n);
+        nl = n;  // tracer.cu:126-127
+        objcol = V3(P.tri_col[0], P.tri_col[1], P.tri_col[2]);
+        emit = V3(P.tri_emi[0], P.tri_emi[1], P.tri_emi[2]);
+        mat = P.tri_mat;
+    } else {
+        col_out = V3(P.bk[0], P.bk[1], P.bk[2]);  // tracer.cu:140-142: unmasked background
+        return true;
+    }
+    accu = vadd(accu, vmul(mask, emit));
+
+    v3 nextdir;
+    if (mat == PT_MAT_DIFF) {  // tracer.cu:156-186
+        (void)pt_rng_next(rng);
+        (void)pt_rng_next(rng);
+        v3 nt = fabsf(nl.x) > fabsf(nl.y) ? V3(nl.z, 0.f, -nl.x) : V3(0.f, -nl.z, nl.y);
+        nt = vnormalize(nt);
+        const v3 nb = vnormalize(vcross(nl, nt));
+        const float f1 = pt_rng_next(rng), f2 = pt_rng_next(rng);
+        float c, s;
+        pt_sincos2pi(f1, c, s);
+        const v3 rv = V3(c * f2, sqrtf(1.0f - f2 * f2), s * f2);  // cudaUtils.h:185-192
+        nextdir = vnormalize(vmadd(nt, rv.z, vmadd(nl, rv.y, vscale(nb, rv.x))));
+        hitpos = vmadd(nl, 0.001f, hitpos);
+        mask = vmul(mask, objcol);
+    } else if (mat == PT_MAT_SPEC) {  // :190-203
+        nextdir = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
+        hitpos = vmadd(nl, 0.001f, hitpos);
+        mask = vmul(mask, objcol);
+    } else if (mat == PT_MAT_REFR) {  // :205-256
+        const bool into = vdot(n, nl) > 0;
+        const float nc = P.air_ior, ntt = P.glass_ior;
+        const float nnt = into ? nc / ntt : ntt / nc;
+        const float ddn = vdot(d, nl);
+        const float cos2t = 1.0f - nnt * nnt * (1.0f - ddn * ddn);
+        if (cos2t < 0.0f) {
+            nextdir = vnormalize(vmadd(n, -2.0f * vdot(n, d), d));
+            hitpos = vmadd(nl, 0.001f, hitpos);
+        } else {
+            const float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
+            const v3 tdir = vnormalize(vmadd(n, -k, vscale(d, nnt)));
+            const float R0 = (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc);  // sic, :230
+            const float c = 1.0f - (into ? -ddn : vdot(tdir, n));
+            const float Re = R0 + (1.0f - R0) * c * c * c * c * c;
+            const float Tr = 1 - Re;
+            const float Pp = 0.25f + 0.5f * Re;
+            const float RP = Re / Pp, TP = Tr / (1.0f - Pp);
+            if (pt_rng_next(rng) < 0.2f) {
+                mask = vscale(mask, RP);
+                nextdir = vnormalize(vmadd(n, -2.0f * vdot(n, d), d));
+            } else {
+                mask = vscale(mask, TP);
+                nextdir = vnormalize(tdir);
+            }
+            hitpos = vmadd(nl, 0.001f, hitpos);
+        }
+    } else {  // METAL :257-293
+        const float f1 = pt_rng_next(rng), r2 = pt_rng_next(rng);
+        float cphi, sphi;
+        pt_sincos2pi(f1, cphi, sphi);
+        const float cosT = pt_pow01(1.0f - r2, 1.0f / (P.phong + 1.0f));
+        const float sinT = sqrtf(1.0f - cosT * cosT);
+        const v3 w1 = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
+        const v3 ax = ((double)fabsf(w1.x) > 0.1) ? V3(0.f, 1.f, 0.f) : V3(1.f, 0.f, 0.f);
+        const v3 uu = vnormalize(vcross(ax, w1));
+        const v3 vv = vcross(w1, uu);
+        const v3 base = vmadd(vv, sphi * sinT, vscale(uu, cphi * sinT));
+        if (P.flags & PT_FLAG_METAL_LITERAL_W) {
+            const float wc = (float)P.W * cosT;  // tracer.cu:280
+            nextdir = V3(base.x + wc, base.y + wc, base.z + wc);
+        } else {
+            nextdir = vmadd(w1, cosT, base);
+        }
+        nextdir = vnormalize(nextdir);
+        hitpos = vmadd(nl, 0.0001f, hitpos);
+        mask = vmul(mask, objcol);
+    }
+        ps.o = hitpos;
+        ps.d = nextdir;
+    }
+    ps.mask = mask; ps.accu = accu; ps.rng = rng;
+    ps.depth++;
+    if (ps.depth >= P.depth) { col_out = accu; return true; }  // tracer.cu:305
+    return false;
+}
+
+// running mean with per-frame clamp, tracer.cu:386-391
+__device__ __forceinline__ void pt_accumulate(float& ax, float& ay, float& az, v3 col, uint64_t N) {
+    const float fm1 = (float)(N - 1), inv = 1.0f / (float)N;
+    if (N == 1) { ax = 0.f; ay = 0.f; az = 0.f; } else { ax *= fm1; ay *= fm1; az *= fm1; }
+    ax = pt_clamp01((ax + col.x) * inv);
+    ay = pt_clamp01((ay + col.y) * inv);
+    az = pt_clamp01((az + col.z) * inv);
+}
+
+// 8-bit truncating pack 0x00BBGGRR, tracer.cu:394-398 + cudaUtils.h:99-105
+__device__ __forceinline__ uint32_t pt_pack_rgba(float ax, float ay, float az) {
+    const uint32_t r = (uint32_t)(unsigned char)(255.0f * ax);
+    const uint32_t g = (uint32_t)(unsigned char)(255.0f * ay);
+    const uint32_t b = (uint32_t)(unsigned char)(255.0f * az);
+    return (b << 16) | (g << 8) | r;
+}
+
+template <bool COUNT, class STK>
+__device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, uint64_t pix, uint64_t frame,
+                                            STK& stk, const float4* __restrict__ s_top, TravCount& tc,
+                                            uint32_t& n_rays, uint32_t& n_hits) {
+    PathState ps;
+    path_begin(P, px, py, pix, frame, ps);
     const bool cull = P.cull != 0;
-
-    for (uint32_t depth = 0; depth < P.depth; ++depth) {
-        int geom = 3;  // GeoType::NONE
-        int sph_id = -1;
+    v3 col = V3(0.f, 0.f, 0.f);
+    if (P.depth == 0) return col;
+    for (;;) {
         Hit h;
         h.t = PT_F32_MAX; h.tri = -1; h.n = V3(0.f, 0.f, 0.f);
-        if (P.sc.has_bvh) h = trav_bvh2<COUNT>(P.sc, o, d, cull, stk, tc);
+        if (P.sc.has_bvh) h = trav_bvh2<COUNT, true, STK>(P.sc, ps.o, ps.d, cull, stk, tc, s_top);
         if (COUNT) { n_rays++; n_hits += (h.tri != -1); }
-        float scene_t = h.t;
-        if (h.tri != -1) geom = 0;
-        // intersectAllSpeheres, cudaUtils.h:221-236 (uniform loop, scalar loads)
-        for (int i = 0; i < P.sc.n_spheres; i++) {
-            const pt_sphere_d& s = P.sc.spheres[i];
-            const float ts = pt_sphere_intersect(s.px, s.py, s.pz, s.rad, o, d);
-            if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
-        }
-        v3 hitpos = vmadd(d, scene_t, o);
-        v3 n, nl, objcol, emit;
-        int mat;
-        if (geom == 1) {
-            const pt_sphere_d& s = P.sc.spheres[sph_id];
-            n = vnormalize(vsub(hitpos, V3(s.px, s.py, s.pz)));
-            nl = vdot(n, d) < 0 ? n : vscale(n, -1.0f);
-            objcol = V3(s.col[0], s.col[1], s.col[2]);
-            emit = V3(s.emi[0], s.emi[1], s.emi[2]);
-            mat = s.mat;
-        } else if (geom == 0) {
-            n = vnormalize(h.n);
-            nl = n;  // tracer.cu:126-127
-            objcol = V3(P.tri_col[0], P.tri_col[1], P.tri_col[2]);
-            emit = V3(P.tri_emi[0], P.tri_emi[1], P.tri_emi[2]);
-            mat = P.tri_mat;
-        } else {
-            return V3(P.bk[0], P.bk[1], P.bk[2]);  // tracer.cu:140-142: unmasked background
-        }
-        accu = vadd(accu, vmul(mask, emit));
-
-        v3 nextdir;
-        if (mat == PT_MAT_DIFF) {  // tracer.cu:156-186
-            (void)pt_rng_next(rng);
-            (void)pt_rng_next(rng);
-            v3 nt = fabsf(nl.x) > fabsf(nl.y) ? V3(nl.z, 0.f, -nl.x) : V3(0.f, -nl.z, nl.y);
-            nt = vnormalize(nt);
-            const v3 nb = vnormalize(vcross(nl, nt));
-            const float f1 = pt_rng_next(rng), f2 = pt_rng_next(rng);
-            float c, s;
-            pt_sincos2pi(f1, c, s);
-            const v3 rv = V3(c * f2, sqrtf(1.0f - f2 * f2), s * f2);  // cudaUtils.h:185-192
-            nextdir = vnormalize(vmadd(nt, rv.z, vmadd(nl, rv.y, vscale(nb, rv.x))));
-            hitpos = vmadd(nl, 0.001f, hitpos);
-            mask = vmul(mask, objcol);
-        } else if (mat == PT_MAT_SPEC) {  // :190-203
-            nextdir = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
-            hitpos = vmadd(nl, 0.001f, hitpos);
-            mask = vmul(mask, objcol);
-        } else if (mat == PT_MAT_REFR) {  // :205-256
-            const bool into = vdot(n, nl) > 0;
-            const float nc = P.air_ior, ntt = P.glass_ior;
-            const float nnt = into ? nc / ntt : ntt / nc;
-            const float ddn = vdot(d, nl);
-            const float cos2t = 1.0f - nnt * nnt * (1.0f - ddn * ddn);
-            if (cos2t < 0.0f) {
-                nextdir = vnormalize(vmadd(n, -2.0f * vdot(n, d), d));
-                hitpos = vmadd(nl, 0.001f, hitpos);
-            } else {
-                const float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
-                const v3 tdir = vnormalize(vmadd(n, -k, vscale(d, nnt)));
-                const float R0 = (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc);  // sic, :230
-                const float c = 1.0f - (into ? -ddn : vdot(tdir, n));
-                const float Re = R0 + (1.0f - R0) * c * c * c * c * c;
-                const float Tr = 1 - Re;
-                const float Pp = 0.25f + 0.5f * Re;
-                const float RP = Re / Pp, TP = Tr / (1.0f - Pp);
-                if (pt_rng_next(rng) < 0.2f) {
-                    mask = vscale(mask, RP);
-                    nextdir = vnormalize(vmadd(n, -2.0f * vdot(n, d), d));
-                } else {
-                    mask = vscale(mask, TP);
-                    nextdir = vnormalize(tdir);
-                }
-                hitpos = vmadd(nl, 0.001f, hitpos);
-            }
-        } else {  // METAL :257-293
-            const float f1 = pt_rng_next(rng), r2 = pt_rng_next(rng);
-            float cphi, sphi;
-            pt_sincos2pi(f1, cphi, sphi);
-            const float cosT = pt_pow01(1.0f - r2, 1.0f / (P.phong + 1.0f));
-            const float sinT = sqrtf(1.0f - cosT * cosT);
-            const v3 w1 = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
-            const v3 ax = ((double)fabsf(w1.x) > 0.1) ? V3(0.f, 1.f, 0.f) : V3(1.f, 0.f, 0.f);
-            const v3 uu = vnormalize(vcross(ax, w1));
-            const v3 vv = vcross(w1, uu);
-            const v3 base = vmadd(vv, sphi * sinT, vscale(uu, cphi * sinT));
-            if (P.flags & PT_FLAG_METAL_LITERAL_W) {
-                const float wc = (float)P.W * cosT;  // tracer.cu:280
-                nextdir = V3(base.x + wc, base.y + wc, base.z + wc);
-            } else {
-                nextdir = vmadd(w1, cosT, base);
-            }
-            nextdir = vnormalize(nextdir);
-            hitpos = vmadd(nl, 0.0001f, hitpos);
-            mask = vmul(mask, objcol);
-        }
-        o = hitpos;
-        d = nextdir;
+        if (path_shade(P, ps, h, col)) break;
     }
-    return accu;
+    return col;
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -289,9 +437,11 @@ __device__ __forceinline__ bool pt_tile_coords(const KParams& P, int tile, int& 
 
 // trace<<<>>>, tracer.cu:343-400: one lane per pixel, one wave per 8x8 tile, `spp`
 // consecutive samples folded in registers.
-template <int STACK, bool COUNT>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace_mega_bvh2(const KParams P) {
-    __shared__ int s_stack[STACK * PT_BLOCK];
+// OCC = waves per SIMD the register allocator must leave room for (4 / 6 / 8)
+template <bool COUNT, int OCC, int LSTK>
+__global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams P) {
+    float4* s_top = s_dyn;
+    lds_load_top<PT_BLOCK>(P.sc, s_top);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int tile = blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
@@ -300,7 +450,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace_mega_bvh2(const KParams P) {
     const int px = tx * PT_TILE + (lane & 7), py = ty * PT_TILE + (lane >> 3);
     if (px >= P.W || py >= P.H) return;  // tracer.cu:358
     const uint64_t pix = (uint64_t)py * (uint64_t)P.W + (uint64_t)px;
-    int* stk = s_stack + tid;
+    TravStack<LSTK, PT_BLOCK> stk;
+    stk.base = 16 * P.sc.n_top + tid;
 
     TravCount tc;
     tc.inner = tc.tris = tc.leaves = 0;
@@ -310,23 +461,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace_mega_bvh2(const KParams P) {
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
     for (uint32_t s = 0; s < P.spp; s++) {
-        pt_rng rng = pt_rng_init(pt_wang64(P.frame + s), pix);  // tracer.cu:362-363
-        const v3 col = pt_get_sample<COUNT>(P, px, py, rng, stk, tc, n_rays, n_hits);
-        // running mean with per-frame clamp, tracer.cu:386-391
-        const uint64_t N = P.sample_index + s;
-        const float fm1 = (float)(N - 1), inv = 1.0f / (float)N;
-        if (N == 1) { ax = 0.f; ay = 0.f; az = 0.f; } else { ax *= fm1; ay *= fm1; az *= fm1; }
-        ax = pt_clamp01((ax + col.x) * inv);
-        ay = pt_clamp01((ay + col.y) * inv);
-        az = pt_clamp01((az + col.z) * inv);
+        const v3 col = pt_get_sample<COUNT>(P, px, py, pix, P.frame + s, stk, s_top, tc, n_rays, n_hits);
+        pt_accumulate(ax, ay, az, col, P.sample_index + s);
     }
     acc[0] = ax; acc[1] = ay; acc[2] = az;
-    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) {  // tracer.cu:394-398, cudaUtils.h:99-105
-        const uint32_t r = (uint32_t)(unsigned char)(255.0f * ax);
-        const uint32_t g = (uint32_t)(unsigned char)(255.0f * ay);
-        const uint32_t b = (uint32_t)(unsigned char)(255.0f * az);
-        P.rgba[pix] = (b << 16) | (g << 8) | r;
-    }
+    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
     if (COUNT) {
         const uint32_t a = wave_sum_u32(n_rays), b = wave_sum_u32(tc.inner), c = wave_sum_u32(tc.tris);
         const uint32_t dd = wave_sum_u32(tc.leaves), e = wave_sum_u32(n_hits), f = wave_sum_u32(P.spp);
@@ -342,18 +481,180 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace_mega_bvh2(const KParams P) {
 }
 
 // Closest-hit on an explicit ray batch (pt_trace_rays): rows a5–a7 in isolation.
-template <int STACK>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace_rays_bvh2(const KScene sc, const float4* __restrict__ rays, size_t n,
-                                                              int cull, float* __restrict__ t_out,
-                                                              int* __restrict__ tri_out, float* __restrict__ n_out) {
-    __shared__ int s_stack[STACK * PT_BLOCK];
-    const size_t i = (size_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+__global__ void __launch_bounds__(PT_BLOCK_RAYS) k_trace_rays_bvh2(const KScene sc, const float4* __restrict__ rays, size_t n,
+                                                                   int cull, float* __restrict__ t_out,
+                                                                   int* __restrict__ tri_out, float* __restrict__ n_out) {
+    float4* s_top = s_dyn;
+    lds_load_top<PT_BLOCK_RAYS>(sc, s_top);
+    const size_t i = (size_t)blockIdx.x * PT_BLOCK_RAYS + threadIdx.x;
     if (i >= n) return;
     const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
     TravCount tc;
     tc.inner = tc.tris = tc.leaves = 0;
-    const Hit h = trav_bvh2<false>(sc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), cull != 0, s_stack + threadIdx.x, tc);
+    TravStack<PT_STACK_CAP, PT_BLOCK_RAYS> stk;
+    stk.base = 16 * sc.n_top + (int)threadIdx.x;
+    const Hit h = trav_bvh2<false, true>(sc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), cull != 0, stk, tc, s_top);
     t_out[i] = h.t;
     tri_out[i] = h.tri;
     if (n_out) { n_out[3 * i] = h.n.x; n_out[3 * i + 1] = h.n.y; n_out[3 * i + 2] = h.n.z; }
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent-waves variant (Aila-Laine "persistent threads", which the reference does NOT
+// have: SURVEY.md F5).  grid = resident waves only; each wave pulls chunks of PT_CHUNK
+// tile-ordered pixel slots from one global counter and keeps every lane busy:
+//   A. refill  — idle lanes take the next slots of the wave's chunk; the lane→slot map is a
+//                ballot + prefix-count (mbcnt) compaction of the idle mask
+//   B. walk    — lanes with a ray in flight run the resumable closest-hit walk; the wave
+//                leaves it as soon as `batch` lanes are waiting for service
+//   C. shade   — lanes whose walk finished do spheres/shading/BRDF and either get their next
+//                segment (back to B) or fold the sample into the accumulator and go idle
+// A lane's ray no longer waits for the slowest ray of its 8x8 tile at every bounce.  Each
+// pixel still sees exactly the arithmetic of k_trace_mega_bvh2 (RNG keyed by pixel, same
+// walk), so the image is bit-identical; only the schedule differs.
+#define PT_CHUNK 256
+enum { PH_IDLE = 0, PH_TRAV = 1, PH_SHADE = 2 };
+
+template <bool COUNT, int OCC, int LSTK>
+__global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KParams P) {
+    float4* s_top = s_dyn;
+    lds_load_top<PT_BLOCK>(P.sc, s_top);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    TravStack<LSTK, PT_BLOCK> stk;
+    stk.base = 16 * P.sc.n_top + tid;
+    const bool cull = P.cull != 0;
+    const uint32_t total = (uint32_t)P.n_tiles * 64u;
+
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool queue_empty = false;                // wave-uniform
+
+    int phase = PH_IDLE;
+    uint32_t pix = 0, s_idx = 0;
+    int px = 0, py = 0;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    PathState ps;
+    TravState ts;
+    ps.o = ps.d = ps.mask = ps.accu = V3(0.f, 0.f, 0.f);
+    ps.depth = 0; ps.rng.s0 = ps.rng.s1 = ps.rng.n = 0;
+    ts.idx = ts.idy = ts.idz = ts.oodx = ts.oody = ts.oodz = 0.f;
+    ts.node = PT_SENTINEL; ts.leaf = 0; ts.sp = 0;
+    ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.n = V3(0.f, 0.f, 0.f);
+
+    TravCount tc;
+    tc.inner = tc.tris = tc.leaves = 0;
+    uint32_t n_rays = 0, n_hits = 0, n_paths = 0;
+
+    for (;;) {
+        // ---- A. refill idle lanes (all 64 lanes are converged here)
+        const unsigned long long idle = __ballot(phase == PH_IDLE);
+        const int n_idle = __popcll(idle);
+        if (!queue_empty && n_idle > 0) {
+            if (chunk_next == chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.queue, (unsigned int)PT_CHUNK);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= total) {
+                    queue_empty = true;
+                } else {
+                    chunk_next = base;
+                    chunk_end = min(base + (uint32_t)PT_CHUNK, total);
+                }
+            }
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t take = min((uint32_t)n_idle, avail);
+            if (phase == PH_IDLE) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (rank < take) {
+                    const uint32_t q = chunk_next + rank;
+                    int tx, ty;
+                    if (pt_tile_coords(P, (int)(q >> 6), tx, ty)) {
+                        px = tx * PT_TILE + (int)(q & 7u);
+                        py = ty * PT_TILE + (int)((q >> 3) & 7u);
+                        if (px < P.W && py < P.H) {  // tracer.cu:358
+                            pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
+                            s_idx = 0;
+                            ax = ay = az = 0.f;
+                            if (P.sample_index != 1) {
+                                const float* acc = P.accum + 3 * (size_t)pix;
+                                ax = acc[0]; ay = acc[1]; az = acc[2];
+                            }
+                            phase = PH_SHADE;  // "needs a new sample": handled at the top of C
+                            ps.depth = 0xffffffffu;
+                        }
+                    }
+                }
+            }
+            chunk_next += take;
+        }
+
+        // ---- C0. lanes that start a sample: camera ray, then walk (or straight to shading)
+        if (phase == PH_SHADE && ps.depth == 0xffffffffu) {
+            path_begin(P, px, py, (uint64_t)pix, P.frame + s_idx, ps);
+            if (P.depth == 0) {
+                ps.depth = 0;
+                phase = PH_SHADE;
+                ts.h.t = PT_F32_MAX; ts.h.tri = -1;
+            } else if (P.sc.has_bvh) {
+                trav_begin(ts, ps.o, ps.d, stk);
+                phase = PH_TRAV;
+            } else {
+                ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.n = V3(0.f, 0.f, 0.f);
+                phase = PH_SHADE;
+            }
+        }
+
+        // ---- B. closest-hit walk for the lanes with a segment in flight
+        {
+            const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
+            if (phase == PH_TRAV) {
+                if (trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top)) phase = PH_SHADE;
+            }
+        }
+
+        // ---- C. shade finished segments
+        if (phase == PH_SHADE && ps.depth != 0xffffffffu) {
+            v3 col = V3(0.f, 0.f, 0.f);
+            bool done;
+            if (P.depth == 0) {
+                done = true;
+            } else {
+                if (COUNT) { n_rays++; n_hits += (ts.h.tri != -1); }
+                done = path_shade(P, ps, ts.h, col);
+            }
+            if (!done) {
+                if (P.sc.has_bvh) {
+                    trav_begin(ts, ps.o, ps.d, stk);
+                    phase = PH_TRAV;
+                }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
+            } else {
+                pt_accumulate(ax, ay, az, col, P.sample_index + s_idx);
+                if (COUNT) n_paths++;
+                s_idx++;
+                if (s_idx < P.spp) {
+                    ps.depth = 0xffffffffu;  // next sample of the same pixel
+                } else {
+                    float* acc = P.accum + 3 * (size_t)pix;
+                    acc[0] = ax; acc[1] = ay; acc[2] = az;
+                    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
+                    phase = PH_IDLE;
+                }
+            }
+        }
+
+        if (queue_empty && !__ballot(phase != PH_IDLE)) break;
+    }
+
+    if (COUNT) {
+        const uint32_t a = wave_sum_u32(n_rays), b = wave_sum_u32(tc.inner), c = wave_sum_u32(tc.tris);
+        const uint32_t dd = wave_sum_u32(tc.leaves), e = wave_sum_u32(n_hits), f = wave_sum_u32(n_paths);
+        if (lane == 0) {
+            atomicAdd(&P.counters[0], (unsigned long long)a);
+            atomicAdd(&P.counters[1], (unsigned long long)b);
+            atomicAdd(&P.counters[2], (unsigned long long)c);
+            atomicAdd(&P.counters[3], (unsigned long long)dd);
+            atomicAdd(&P.counters[4], (unsigned long long)e);
+            atomicAdd(&P.counters[5], (unsigned long long)f);
+        }
+    }
 }

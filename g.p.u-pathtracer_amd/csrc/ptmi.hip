@@ -34,6 +34,7 @@ struct pt_ctx {
     int n_spheres = 0;
     uint64_t n_inner = 0, n_refs = 0, n_leaves = 0, scene_bytes = 0;
     uint32_t max_depth = 0;
+    uint32_t n_top_layout = 0;   // nodes [0, n_top_layout) are in breadth-first order
     bool has_bvh = false;
     // options
     int opt_kernel = PT_KERNEL_AUTO;
@@ -41,6 +42,12 @@ struct pt_ctx {
     int opt_timing = 0;
     // measurement
     unsigned long long* d_counters = nullptr;
+    unsigned int* d_queue = nullptr;   // persistent kernel's work counter
+    int n_cu = 0;
+    int opt_batch = 16;
+    int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
+    int opt_occ = 8;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
+    int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 };
@@ -70,10 +77,12 @@ int stack_for_depth(uint32_t depth) {
     return 72;
 }
 
-template <int STACK>
-static void launch_mega(pt_ctx* c, const KParams& P, int blocks) {
-    if (c->opt_counters) hipLaunchKernelGGL((k_trace_mega_bvh2<STACK, true>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, P);
-    else hipLaunchKernelGGL((k_trace_mega_bvh2<STACK, false>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, P);
+// LDS bytes of a frame-kernel block: top-of-tree planes + stack
+size_t lds_bytes(int n_top, int stack_n, int block) { return (size_t)n_top * 64 + (size_t)stack_n * block * 4; }
+
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace
@@ -104,6 +113,10 @@ int pt_create(int device, pt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;
     if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
+    if ((e = hipMalloc(&c->d_queue, 64)) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipGetDeviceProperties"); }
+    c->n_cu = prop.multiProcessorCount;
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
     *out = c;
@@ -118,6 +131,7 @@ int pt_destroy(pt_ctx* c) {
     (void)hipFree(c->d_tris);
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_queue);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -135,12 +149,28 @@ int pt_set_option(pt_ctx* c, int option, int value) {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
     switch (option) {
         case PT_OPT_KERNEL:
-            if (value != PT_KERNEL_AUTO && value != PT_KERNEL_MEGA_BVH2)
+            if (value != PT_KERNEL_AUTO && value != PT_KERNEL_MEGA_BVH2 && value != PT_KERNEL_PERSISTENT)
                 return fail(c, PT_ERR_UNSUPPORTED, "pt_set_option: kernel variant not available in this build");
             c->opt_kernel = value;
             return PT_OK;
         case PT_OPT_COUNTERS: c->opt_counters = value != 0; return PT_OK;
         case PT_OPT_TIMING: c->opt_timing = value != 0; return PT_OK;
+        case PT_OPT_TOP_NODES:
+            if (value < 0 || value > PT_MAX_TOP) return fail(c, PT_ERR_INVALID, "pt_set_option: top nodes must be 0..1024");
+            c->opt_top = value;
+            return PT_OK;
+        case PT_OPT_OCCUPANCY:
+            if (value != 4 && value != 6 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: occupancy must be 4, 6 or 8 waves per SIMD");
+            c->opt_occ = value;
+            return PT_OK;
+        case PT_OPT_LDS_STACK:
+            if (value != 0 && value != 16 && value != 32) return fail(c, PT_ERR_INVALID, "pt_set_option: LDS stack must be 0 (all 72 entries in LDS), 16 or 32 entries");
+            c->opt_lstk = value;
+            return PT_OK;
+        case PT_OPT_BATCH:
+            if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: batch must be 1..64");
+            c->opt_batch = value;
+            return PT_OK;
         default: return fail(c, PT_ERR_INVALID, "pt_set_option: unknown option");
     }
 }
@@ -188,8 +218,9 @@ int pt_upload(pt_ctx* c, void* dst, const void* src, size_t bytes) {
 // ---------------------------------------------------------------------------------------
 // Scene upload: validate the reference Compact arrays (CudaBVH.cpp:121-270), then re-lay
 // them out for the gfx950 kernels:
-//   nodes  : same 64-byte record, children in depth-first order (parent next to its first
-//            inner child), links rewritten from byte offsets to float4 indices
+//   nodes  : same 64-byte record; the top PT_MAX_TOP nodes in breadth-first order (any prefix
+//            of them can be mirrored in LDS), the rest depth-first (a parent next to its first
+//            inner child); links rewritten from byte offsets to float4 indices
 //   tris   : 48-byte records {v0.xyz, id | e1.xyz, last | e2.xyz, 0}: the edge subtraction
 //            of cudaUtils.h:177-178 is hoisted to upload (same IEEE result), the index
 //            remap of :452-456 and the 16-byte terminator fetch of :410-413 disappear
@@ -244,45 +275,82 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
         return true;
     };
 
-    struct Item { size_t old_node; size_t new_node; uint32_t depth; };
-    std::vector<Item> stack;
-    new_index[0] = 0;
-    out_nodes.resize(16, 0.f);
-    stack.push_back({0, 0, 0});
-    size_t n_out = 1;
-    while (!stack.empty()) {
-        Item it = stack.back();
-        stack.pop_back();
-        const float* src = nodes + 16 * it.old_node;
-        int32_t link[2] = {bits(src[12]), bits(src[13])};
-        int32_t new_link[2];
-        // child 1 first so that child 0 is popped (and numbered) right after its parent
-        for (int i = 1; i >= 0; i--) {
-            if (link[i] >= 0) {
-                if ((link[i] % 64) != 0 || (size_t)link[i] / 64 >= n_nodes_in)
-                    return fail(c, PT_ERR_INVALID, "pt_upload_bvh: child link is not a valid node byte offset");
-                const size_t child = (size_t)link[i] / 64;
-                if (new_index[child] != -1) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node referenced twice (not a tree)");
-                new_index[child] = (int32_t)n_out;
-                new_link[i] = (int32_t)(n_out * 4);  // float4 index
-                stack.push_back({child, n_out, it.depth + 1});
-                n_out++;
-                out_nodes.resize(n_out * 16, 0.f);
-            } else {
-                if (!emit_leaf(link[i], new_link[i])) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: leaf runs past the triangle array");
-                max_depth = std::max(max_depth, it.depth + 1);
+    // pass 1 (depth-first): validate links, emit leaves in tree order, record depths
+    std::vector<int32_t> leaf_link(2 * n_nodes_in, 0);
+    std::vector<uint32_t> depth(n_nodes_in, 0);
+    std::vector<uint8_t> seen(n_nodes_in, 0);
+    {
+        std::vector<size_t> stack{0};
+        seen[0] = 1;
+        while (!stack.empty()) {
+            const size_t u = stack.back();
+            stack.pop_back();
+            const float* src = nodes + 16 * u;
+            const int32_t link[2] = {bits(src[12]), bits(src[13])};
+            for (int i = 0; i < 2; i++) {
+                if (link[i] >= 0) {
+                    if ((link[i] % 64) != 0 || (size_t)link[i] / 64 >= n_nodes_in)
+                        return fail(c, PT_ERR_INVALID, "pt_upload_bvh: child link is not a valid node byte offset");
+                    const size_t child = (size_t)link[i] / 64;
+                    if (seen[child]) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node referenced twice (not a tree)");
+                    seen[child] = 1;
+                    depth[child] = depth[u] + 1;
+                    if (depth[child] > 64) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: tree deeper than 64 (SplitBVHBuilder MaxDepth)");
+                } else {
+                    if (!emit_leaf(link[i], leaf_link[2 * u + i])) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: leaf runs past the triangle array");
+                    max_depth = std::max(max_depth, depth[u] + 1);
+                }
+            }
+            for (int i = 1; i >= 0; i--)  // child 0 is walked first
+                if (link[i] >= 0) stack.push_back((size_t)link[i] / 64);
+        }
+    }
+    // pass 2: new numbering = breadth-first for the top PT_MAX_TOP nodes (the LDS mirror is
+    // any prefix of it), depth-first below (a parent next to its first inner child)
+    std::vector<size_t> order;
+    order.reserve(n_nodes_in);
+    {
+        std::vector<size_t> frontier{0};
+        size_t head = 0;
+        while (head < frontier.size() && order.size() < (size_t)PT_MAX_TOP) {
+            const size_t u = frontier[head++];
+            new_index[u] = (int32_t)order.size();
+            order.push_back(u);
+            const float* src = nodes + 16 * u;
+            for (int i = 0; i < 2; i++) {
+                const int32_t l = bits(src[12 + i]);
+                if (l >= 0) frontier.push_back((size_t)l / 64);
             }
         }
-        float* dst = &out_nodes[16 * it.new_node];
-        std::memcpy(dst, src, 12 * sizeof(float));
-        dst[12] = fbits(new_link[0]);
-        dst[13] = fbits(new_link[1]);
-        dst[14] = 0.f;
-        dst[15] = 0.f;
+        const size_t n_bfs = order.size();
+        for (; head < frontier.size(); head++) {
+            std::vector<size_t> stack{frontier[head]};
+            while (!stack.empty()) {
+                const size_t u = stack.back();
+                stack.pop_back();
+                new_index[u] = (int32_t)order.size();
+                order.push_back(u);
+                const float* src = nodes + 16 * u;
+                for (int i = 1; i >= 0; i--) {
+                    const int32_t l = bits(src[12 + i]);
+                    if (l >= 0) stack.push_back((size_t)l / 64);
+                }
+            }
+        }
+        c->n_top_layout = (uint32_t)n_bfs;
     }
-    // numbering above follows push order, not pop order; renumber depth-first for locality
-    // (kept simple: push order already places siblings together and subtrees contiguously
-    // enough for the 64-byte gathers; see DESIGN.md §3 for the measured alternatives)
+    const size_t n_out = order.size();
+    out_nodes.assign(n_out * 16, 0.f);
+    for (size_t k = 0; k < n_out; k++) {
+        const size_t u = order[k];
+        const float* src = nodes + 16 * u;
+        float* dst = &out_nodes[16 * k];
+        std::memcpy(dst, src, 12 * sizeof(float));
+        for (int i = 0; i < 2; i++) {
+            const int32_t l = bits(src[12 + i]);
+            dst[12 + i] = fbits(l >= 0 ? new_index[(size_t)l / 64] * 4 : leaf_link[2 * u + i]);  // float4 index | ~record
+        }
+    }
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -384,12 +452,59 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    switch (stack_for_depth(c->has_bvh ? c->max_depth : 0)) {
-        case 24: launch_mega<24>(c, P, blocks); break;
-        case 32: launch_mega<32>(c, P, blocks); break;
-        case 48: launch_mega<48>(c, P, blocks); break;
-        default: launch_mega<72>(c, P, blocks); break;
+    const bool persistent = c->opt_kernel == PT_KERNEL_PERSISTENT;
+    const int need = stack_for_depth(c->has_bvh ? c->max_depth : 0);
+    (void)need;  // any depth <= 64 works with every LDS window: deeper entries overflow
+    int lstk = c->opt_lstk ? c->opt_lstk : PT_STACK_CAP;
+    P.sc.stack_n = lstk;
+    P.sc.n_top = c->has_bvh ? (int)std::min<uint32_t>((uint32_t)c->opt_top, c->n_top_layout) : 0;
+    size_t lds = lds_bytes(P.sc.n_top, lstk, PT_BLOCK);
+    while (lds > 160 * 1024 && P.sc.n_top > 0) {  // deep tree: give the LDS to the stack first
+        P.sc.n_top /= 2;
+        lds = lds_bytes(P.sc.n_top, lstk, PT_BLOCK);
     }
+    if (persistent) {
+        P.queue = c->d_queue;
+        P.batch = c->opt_batch;
+        HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
+    }
+    const int work_blocks = (P.n_tiles * 64 + PT_CHUNK * (PT_BLOCK / 64) - 1) / (PT_CHUNK * (PT_BLOCK / 64));
+    // persistent grid: as many blocks as can be resident (no grid-wide wait anywhere, so an
+    // over-estimate only means a few late blocks find the queue empty and exit)
+#define PT_LAUNCH(COUNT, OCC, LSTK)                                                                              \
+    do {                                                                                                         \
+        if (persistent) {                                                                                        \
+            int per_cu = 0;                                                                                      \
+            HIP_TRY(c, allow_lds(k_trace_persist_bvh2<COUNT, OCC, LSTK>, lds));                                  \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persist_bvh2<COUNT, OCC, LSTK>,    \
+                                                             PT_BLOCK, lds) != hipSuccess || per_cu < 1)        \
+                per_cu = 1;                                                                                      \
+            hipLaunchKernelGGL((k_trace_persist_bvh2<COUNT, OCC, LSTK>),                                         \
+                               dim3(std::min(per_cu * c->n_cu, std::max(1, work_blocks))), dim3(PT_BLOCK), lds,  \
+                               c->stream, P);                                                                    \
+        } else {                                                                                                 \
+            HIP_TRY(c, allow_lds(k_trace_mega_bvh2<COUNT, OCC, LSTK>, lds));                                     \
+            hipLaunchKernelGGL((k_trace_mega_bvh2<COUNT, OCC, LSTK>), dim3(blocks), dim3(PT_BLOCK), lds,         \
+                               c->stream, P);                                                                    \
+        }                                                                                                        \
+    } while (0)
+#define PT_LAUNCH_OCC(COUNT, LSTK)                       \
+    do {                                                 \
+        if (c->opt_occ == 8) PT_LAUNCH(COUNT, 8, LSTK);  \
+        else if (c->opt_occ == 6) PT_LAUNCH(COUNT, 6, LSTK); \
+        else PT_LAUNCH(COUNT, 4, LSTK);                  \
+    } while (0)
+    if (c->opt_counters) {
+        if (lstk == 16) PT_LAUNCH_OCC(true, 16);
+        else if (lstk == 32) PT_LAUNCH_OCC(true, 32);
+        else PT_LAUNCH_OCC(true, PT_STACK_CAP);
+    } else {
+        if (lstk == 16) PT_LAUNCH_OCC(false, 16);
+        else if (lstk == 32) PT_LAUNCH_OCC(false, 32);
+        else PT_LAUNCH_OCC(false, PT_STACK_CAP);
+    }
+#undef PT_LAUNCH_OCC
+#undef PT_LAUNCH
     HIP_TRY(c, hipGetLastError());
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
     return PT_OK;
@@ -402,16 +517,17 @@ int pt_trace_rays(pt_ctx* c, const float* rays_dev, size_t n, int cull, float* t
     if (!rays_dev || !t_dev || !tri_dev) return fail(c, PT_ERR_INVALID, "pt_trace_rays: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
     KScene sc;
+    std::memset(&sc, 0, sizeof sc);
     sc.nodes = c->d_nodes; sc.tris = c->d_tris; sc.spheres = nullptr; sc.n_spheres = 0; sc.has_bvh = 1;
-    const int blocks = (int)((n + PT_BLOCK - 1) / PT_BLOCK);
+    const int blocks = (int)((n + PT_BLOCK_RAYS - 1) / PT_BLOCK_RAYS);
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const float4* r4 = (const float4*)rays_dev;
-    switch (stack_for_depth(c->max_depth)) {
-        case 24: hipLaunchKernelGGL((k_trace_rays_bvh2<24>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
-        case 32: hipLaunchKernelGGL((k_trace_rays_bvh2<32>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
-        case 48: hipLaunchKernelGGL((k_trace_rays_bvh2<48>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
-        default: hipLaunchKernelGGL((k_trace_rays_bvh2<72>), dim3(blocks), dim3(PT_BLOCK), 0, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev); break;
-    }
+    sc.stack_n = PT_STACK_CAP;
+    sc.n_top = (int)std::min<uint32_t>((uint32_t)c->opt_top, c->n_top_layout);
+    size_t lds = lds_bytes(sc.n_top, sc.stack_n, PT_BLOCK_RAYS);
+    while (lds > 160 * 1024 && sc.n_top > 0) { sc.n_top /= 2; lds = lds_bytes(sc.n_top, sc.stack_n, PT_BLOCK_RAYS); }
+    HIP_TRY(c, allow_lds(k_trace_rays_bvh2, lds));
+    hipLaunchKernelGGL(k_trace_rays_bvh2, dim3(blocks), dim3(PT_BLOCK_RAYS), lds, c->stream, sc, r4, n, cull, t_dev, tri_dev, normal_dev);
     HIP_TRY(c, hipGetLastError());
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
     return PT_OK;

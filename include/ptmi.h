@@ -74,7 +74,13 @@ enum {
 enum {
     PT_OPT_KERNEL = 1,        /* one of PT_KERNEL_*                                        */
     PT_OPT_COUNTERS = 2,      /* 1 = instrumented launch: fill pt_counters (slower)         */
-    PT_OPT_TIMING = 3         /* 1 = bracket every launch with hipEvents (pt_last_kernel_ms) */
+    PT_OPT_TIMING = 3,        /* 1 = bracket every launch with hipEvents (pt_last_kernel_ms) */
+    PT_OPT_BATCH = 4,         /* persistent kernel: waiting lanes (1..64) that make a wave
+                                 leave the traversal loop to shade / refill; default 16      */
+    PT_OPT_TOP_NODES = 5,     /* BVH nodes (breadth-first prefix, 0..1024) mirrored in LDS    */
+    PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the kernel's registers are budgeted for: 4/6/8 */
+    PT_OPT_LDS_STACK = 7      /* traversal-stack entries kept in LDS per lane: 16 (default), 32,
+                                 or 0 = all 72; deeper entries overflow to private memory     */
 };
 
 /* CamInfo, GpuPathTracer/CpuStructs.hpp:19-28 (pitch/yaw/dirty/bias/enabled are host-only

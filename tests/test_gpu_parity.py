@@ -26,9 +26,12 @@ def l2(a, b):
     return float(np.sqrt(np.mean(np.sum((a.astype(np.float64) - b) ** 2, axis=-1))))
 
 
-@pytest.fixture(scope="module")
-def pt():
+@pytest.fixture(scope="module", params=[g.KERNEL_PERSISTENT, g.KERNEL_MEGA_BVH2], ids=["persistent", "mega"])
+def pt(request):
+    """Every test runs against both exact kernels: the persistent-waves kernel (the default)
+    and the one-lane-per-pixel megakernel."""
     t = g.PathTracer(0)
+    t.set_option(g.OPT_KERNEL, request.param)
     yield t
     t.close()
 

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 BENCH="python3 $R/bench.py --steps 30 --warmup 5 --cpu-frames 0 --no-cpu-reference --no-extra $*"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 echo "trace done"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" \
@@ -21,8 +21,8 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
     i=$((i+1))
-    rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i ($SET) failed"; tail -3 "$OUT/pmc$i.log"; }
-    echo "pmc pass $i done: $SET"
+    timeout -k 10 150 rocprofv3 --pmc $SET --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i ($SET) failed"; tail -3 "$OUT/pmc$i.log"; }
+    echo "pmc pass $i done: $SET" | tee -a "$OUT/progress.txt"
 done
 python3 "$R/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

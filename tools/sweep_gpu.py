@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel variants / options in ONE process (cdna guide §5.4 rule 24).
+Usage: python tools/sweep_gpu.py [--scene cornell_dragon_800k] [--rounds 5] [--frames 20]"""
+import argparse, os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import gpu_pathtracer_amd as g
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="cornell_dragon_800k")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--frames", type=int, default=20)
+ap.add_argument("--mat", type=int, default=0)
+ap.add_argument("--no-spheres", action="store_true")
+ap.add_argument("--variants", default="mega::0:4:32,mega::64:4:32,mega::0:6:32,mega::0:6:16,mega::64:6:16,mega::0:8:16,mega::64:8:16,persist:16:0:6:16,persist:16:0:8:16",
+                help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack]]]]")
+a = ap.parse_args()
+
+W, H = a.width, a.height
+bvh = g.Bvh(g.scene_mesh(a.scene))
+pt = g.PathTracer(0)
+pt.upload_bvh(bvh)
+pt.upload_spheres(None if a.no_spheres else g.reference_spheres())
+cam = g.default_camera(W, H)
+acc, rgba = pt.alloc_frame(W, H)
+variants = []
+for v in a.variants.split(","):
+    parts = v.split(":") + ["", "", "", ""]
+    variants.append((v, {"mega": g.KERNEL_MEGA_BVH2, "persist": g.KERNEL_PERSISTENT, "wide": g.KERNEL_MEGA_WIDE}[parts[0]],
+                     int(parts[1]) if parts[1] else 16, int(parts[2]) if parts[2] else 64,
+                     int(parts[3]) if parts[3] else 4, int(parts[4]) if parts[4] else 0))
+res = {v[0]: [] for v in variants}
+for r in range(a.rounds + 1):
+    for name, k, batch, top, occ, lstk in variants:
+        pt.set_option(g.OPT_KERNEL, k)
+        pt.set_option(g.OPT_BATCH, batch)
+        pt.set_option(g.OPT_TOP_NODES, top)
+        pt.set_option(g.OPT_OCCUPANCY, occ)
+        pt.set_option(g.OPT_LDS_STACK, lstk)
+        pt.sync()
+        t0 = time.perf_counter()
+        for f in range(a.frames):
+            p = g.default_params(W, H, tri_mat=a.mat)
+            p.frame, p.sample_index = f, 1 + f
+            p.flags = g.FLAG_WRITE_RGBA
+            pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, 1)
+        pt.sync()
+        dt = (time.perf_counter() - t0) / a.frames
+        if r > 0:
+            res[name].append(dt * 1e3)
+print(f"scene {a.scene} {W}x{H} mat {a.mat} spheres {not a.no_spheres}: ms/frame (median, min) and Mrays/s at median (closed-scene bound)")
+for name, v in res.items():
+    med, mn = float(np.median(v)), float(np.min(v))
+    print(f"  {name:22s} median {med:7.3f} ms  min {mn:7.3f} ms   {W * H * 4 / med / 1e3:8.1f} Mrays/s")
