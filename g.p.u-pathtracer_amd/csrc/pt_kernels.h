@@ -16,8 +16,12 @@
 #define PT_STACK_CAP 72       // deepest traversal stack (tree depth <= 64, SplitBVHBuilder MaxDepth)
 
 struct KScene {
-    const float4* __restrict__ nodes;   // 4 float4 per inner node, links = float4 indices
-    const float4* __restrict__ tris;    // 3 float4 per triangle reference (v0|id, e1|last, e2|0)
+    // One buffer of 64-byte items (4 float4 each): inner nodes first, then triangle records
+    //   node: [c0.lo.x c0.hi.x c0.lo.y c0.hi.y][c1 ...][c0.lo.z c0.hi.z c1.lo.z c1.hi.z][link0 link1 0 0]
+    //   tri : [v0.xyz, id][e1.xyz, last][e2.xyz, 0][cross(v0-v1, v0-v2), 0]
+    // links: >= 0 float4 index of an inner node, < 0 ~(float4 index of a leaf's first record)
+    const float4* __restrict__ nodes;   // = items
+    const float4* __restrict__ tris;    // = items (same base: leaf links index the same buffer)
     const pt_sphere_d* __restrict__ spheres;
     int n_spheres;
     int has_bvh;
@@ -191,7 +195,7 @@ __device__ __forceinline__ bool trav_run(TravState& s, const KScene& sc, v3 o, v
         }
         while (leaf < 0) {
             if (COUNT) tc.leaves++;
-            for (int a = ~leaf;; a += 3) {
+            for (int a = ~leaf;; a += 4) {
                 const float4 r0 = sc.tris[a + 0];
                 const float4 r1 = sc.tris[a + 1];
                 const float4 r2 = sc.tris[a + 2];
@@ -202,8 +206,8 @@ __device__ __forceinline__ bool trav_run(TravState& s, const KScene& sc, v3 o, v
                 if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                     h.t = t;
                     h.tri = id;
-                    // cross(v0-v1, v0-v2): v0-v1 = 0-(v1-v0) bit for bit (incl. the sign of zeros)
-                    h.n = vcross(vsub(V3(0.f, 0.f, 0.f), e1), vsub(V3(0.f, 0.f, 0.f), e2));
+                    const float4 r3 = sc.tris[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
+                    h.n = V3(r3.x, r3.y, r3.z);
                 }
                 if (__float_as_int(r1.w) != 0) break;  // last record of the leaf
             }
@@ -220,6 +224,83 @@ __device__ __forceinline__ bool trav_run(TravState& s, const KScene& sc, v3 o, v
     }
     s.node = node; s.leaf = leaf; s.sp = sp; s.h = h;
     return node == PT_SENTINEL;
+}
+
+// ---------------------------------------------------------------------------------------
+// Unified-step walk: every iteration EVERY live lane advances by one 64-byte item — an inner
+// node (two slab tests) or one triangle record (Moller-Trumbore) — fetched by the same four
+// dwordx4 loads.  Why: rocprof shows the CU's vector-memory return path (TD) ~90 % busy at
+// ~16-20 cycles per dwordx4 WAVE instruction whatever the number of active lanes, and the
+// while-while walk above issues those instructions at ~26 % lane utilisation (lanes holding a
+// leaf idle through the node phase and vice versa).  Here one set of four loads serves all 64
+// lanes.  `cur` is the lane's item: >= 0 node, < 0 ~record, sentinel = done.  The set of
+// boxes/triangles a ray tests can differ slightly from the while-while order (a leaf is
+// tested as soon as it is popped, so later nodes see the shorter ray), the closest hit
+// (t, id, normal) cannot: ties go to the smaller id, so the result is order-independent.
+template <bool COUNT, bool DYN, class STK>
+__device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                                 TravCount& tc, int n_dead, int batch) {
+    int cur = s.node, sp = s.sp;
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    while (cur != PT_SENTINEL) {
+        const int a = cur >= 0 ? cur : ~cur;
+        const float4 q0 = sc.nodes[a + 0];
+        const float4 q1 = sc.nodes[a + 1];
+        const float4 q2 = sc.nodes[a + 2];
+        const float4 q3 = sc.nodes[a + 3];
+        if (cur >= 0) {
+            if (COUNT) tc.inner++;
+            int cx = __float_as_int(q3.x), cy = __float_as_int(q3.y);
+            const float c0lox = fmaf(q0.x, idx, -oodx), c0hix = fmaf(q0.y, idx, -oodx);
+            const float c0loy = fmaf(q0.z, idy, -oody), c0hiy = fmaf(q0.w, idy, -oody);
+            const float c1lox = fmaf(q1.x, idx, -oodx), c1hix = fmaf(q1.y, idx, -oodx);
+            const float c1loy = fmaf(q1.z, idy, -oody), c1hiy = fmaf(q1.w, idy, -oody);
+            const float c0loz = fmaf(q2.x, idz, -oodz), c0hiz = fmaf(q2.y, idz, -oodz);
+            const float c1loz = fmaf(q2.z, idz, -oodz), c1hiz = fmaf(q2.w, idz, -oodz);
+            const float c0min = fmaxf(fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fminf(c0loz, c0hiz)), 0.0f);
+            const float c0max = fminf(fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fmaxf(c0loz, c0hiz)), h.t);
+            const float c1min = fmaxf(fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fminf(c1loz, c1hiz)), 0.0f);
+            const float c1max = fminf(fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fmaxf(c1loz, c1hiz)), h.t);
+            const bool t0 = (c0min <= c0max) && (c0min >= 0.0f) && (c0min <= PT_F32_MAX);
+            const bool t1 = (c1min <= c1max) && (c1min >= 0.0f) && (c1min <= PT_F32_MAX);
+            if (!t0 && !t1) {
+                cur = stk.get(sp);
+                sp--;
+            } else {
+                cur = t0 ? cx : cy;
+                if (t0 && t1) {
+                    if (c1min < c0min) { int tmp = cur; cur = cy; cy = tmp; }
+                    sp++;
+                    stk.put(sp, cy);
+                }
+            }
+            if (COUNT && cur < 0) tc.leaves++;
+        } else {
+            if (COUNT) tc.tris++;
+            const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+            const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+            const int id = __float_as_int(q0.w);
+            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                h.t = t;
+                h.tri = id;
+                h.n = V3(q3.x, q3.y, q3.z);
+            }
+            if (__float_as_int(q1.w) != 0) {  // last record of the leaf
+                cur = stk.get(sp);
+                sp--;
+                if (COUNT && cur < 0 && cur != PT_SENTINEL) tc.leaves++;
+            } else {
+                cur -= 4;  // ~(a + 4)
+            }
+        }
+        if (DYN) {  // enough lanes are waiting for service: hand the wave back
+            const int active = __popcll(__ballot(cur != PT_SENTINEL));
+            if (64 - active - n_dead >= batch) break;
+        }
+    }
+    s.node = cur; s.sp = sp; s.h = h;
+    return cur == PT_SENTINEL;
 }
 
 template <bool COUNT, bool TOP, class STK>
@@ -396,7 +477,7 @@ __device__ __forceinline__ uint32_t pt_pack_rgba(float ax, float ay, float az) {
     return (b << 16) | (g << 8) | r;
 }
 
-template <bool COUNT, class STK>
+template <bool COUNT, int ALG, class STK>
 __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, uint64_t pix, uint64_t frame,
                                             STK& stk, const float4* __restrict__ s_top, TravCount& tc,
                                             uint32_t& n_rays, uint32_t& n_hits) {
@@ -408,7 +489,16 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
     for (;;) {
         Hit h;
         h.t = PT_F32_MAX; h.tri = -1; h.n = V3(0.f, 0.f, 0.f);
-        if (P.sc.has_bvh) h = trav_bvh2<COUNT, true, STK>(P.sc, ps.o, ps.d, cull, stk, tc, s_top);
+        if (P.sc.has_bvh) {
+            if (ALG == 1) {
+                TravState ts;
+                trav_begin(ts, ps.o, ps.d, stk);
+                trav_run_unified<COUNT, false, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
+                h = ts.h;
+            } else {
+                h = trav_bvh2<COUNT, true, STK>(P.sc, ps.o, ps.d, cull, stk, tc, s_top);
+            }
+        }
         if (COUNT) { n_rays++; n_hits += (h.tri != -1); }
         if (path_shade(P, ps, h, col)) break;
     }
@@ -438,7 +528,8 @@ __device__ __forceinline__ bool pt_tile_coords(const KParams& P, int tile, int& 
 // trace<<<>>>, tracer.cu:343-400: one lane per pixel, one wave per 8x8 tile, `spp`
 // consecutive samples folded in registers.
 // OCC = waves per SIMD the register allocator must leave room for (4 / 6 / 8)
-template <bool COUNT, int OCC, int LSTK>
+// ALG = 0 while-while walk (Aila-Laine), 1 unified-step walk
+template <bool COUNT, int OCC, int LSTK, int ALG>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams P) {
     float4* s_top = s_dyn;
     lds_load_top<PT_BLOCK>(P.sc, s_top);
@@ -461,7 +552,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
     for (uint32_t s = 0; s < P.spp; s++) {
-        const v3 col = pt_get_sample<COUNT>(P, px, py, pix, P.frame + s, stk, s_top, tc, n_rays, n_hits);
+        const v3 col = pt_get_sample<COUNT, ALG>(P, px, py, pix, P.frame + s, stk, s_top, tc, n_rays, n_hits);
         pt_accumulate(ax, ay, az, col, P.sample_index + s);
     }
     acc[0] = ax; acc[1] = ay; acc[2] = az;
@@ -512,10 +603,10 @@ __global__ void __launch_bounds__(PT_BLOCK_RAYS) k_trace_rays_bvh2(const KScene 
 // A lane's ray no longer waits for the slowest ray of its 8x8 tile at every bounce.  Each
 // pixel still sees exactly the arithmetic of k_trace_mega_bvh2 (RNG keyed by pixel, same
 // walk), so the image is bit-identical; only the schedule differs.
-#define PT_CHUNK 256
+#define PT_CHUNK 64
 enum { PH_IDLE = 0, PH_TRAV = 1, PH_SHADE = 2 };
 
-template <bool COUNT, int OCC, int LSTK>
+template <bool COUNT, int OCC, int LSTK, int ALG>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KParams P) {
     float4* s_top = s_dyn;
     lds_load_top<PT_BLOCK>(P.sc, s_top);
@@ -608,7 +699,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         {
             const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
             if (phase == PH_TRAV) {
-                if (trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top)) phase = PH_SHADE;
+                const bool fin = (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                                            : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
+                if (fin) phase = PH_SHADE;
             }
         }
 

@@ -44,10 +44,11 @@ struct pt_ctx {
     unsigned long long* d_counters = nullptr;
     unsigned int* d_queue = nullptr;   // persistent kernel's work counter
     int n_cu = 0;
-    int opt_batch = 16;
+    int opt_batch = 32;
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
-    int opt_occ = 8;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
+    int opt_occ = 6;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
+    int opt_walk = 1;            // 0 while-while, 1 unified-step (PT_OPT_WALK)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 };
@@ -127,8 +128,7 @@ int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->d_nodes);
-    (void)hipFree(c->d_tris);
+    (void)hipFree(c->d_nodes);  // d_tris aliases it
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_queue);
@@ -163,8 +163,12 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value != 4 && value != 6 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: occupancy must be 4, 6 or 8 waves per SIMD");
             c->opt_occ = value;
             return PT_OK;
+        case PT_OPT_WALK:
+            if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while) or 1 (unified-step)");
+            c->opt_walk = value;
+            return PT_OK;
         case PT_OPT_LDS_STACK:
-            if (value != 0 && value != 16 && value != 32) return fail(c, PT_ERR_INVALID, "pt_set_option: LDS stack must be 0 (all 72 entries in LDS), 16 or 32 entries");
+            if (value != 0 && value != 16) return fail(c, PT_ERR_INVALID, "pt_set_option: LDS stack must be 0 (all 72 entries in LDS) or 16 entries");
             c->opt_lstk = value;
             return PT_OK;
         case PT_OPT_BATCH:
@@ -245,6 +249,29 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
     auto fbits = [](int32_t i) { float f; std::memcpy(&f, &i, 4); return f; };
 
+    // count the reachable nodes first: the triangle records sit behind them in the same buffer
+    size_t tri_base = 0;
+    {
+        std::vector<size_t> st{0};
+        std::vector<uint8_t> mark(n_nodes_in, 0);
+        mark[0] = 1;
+        size_t n_reach = 0;
+        while (!st.empty()) {
+            const size_t u = st.back();
+            st.pop_back();
+            n_reach++;
+            for (int i = 0; i < 2; i++) {
+                const int32_t l = bits(nodes[16 * u + 12 + i]);
+                if (l < 0) continue;
+                if ((l % 64) != 0 || (size_t)l / 64 >= n_nodes_in)
+                    return fail(c, PT_ERR_INVALID, "pt_upload_bvh: child link is not a valid node byte offset");
+                if (mark[(size_t)l / 64]) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node referenced twice (not a tree)");
+                mark[(size_t)l / 64] = 1;
+                st.push_back((size_t)l / 64);
+            }
+        }
+        tri_base = n_reach * 4;  // float4 index of the first record
+    }
     // emits one leaf, returns the link (~first float4 index) or 0 on error
     auto emit_leaf = [&](int32_t link, int32_t& out_link) -> bool {
         size_t a = (size_t)(~link);
@@ -257,21 +284,25 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
             if (w0 == 0x80000000u) break;
             if (a + 2 >= n_tri_vec4) return false;
             const float* v0 = r; const float* v1 = r + 4; const float* v2 = r + 8;
-            float rec[12] = {v0[0], v0[1], v0[2], fbits(tri_index[a]),
+            // cross(v0-v1, v0-v2) with the kernels' vcross arithmetic (cudaUtils.h:432)
+            const float ax = v0[0] - v1[0], ay = v0[1] - v1[1], az = v0[2] - v1[2];
+            const float bx = v0[0] - v2[0], by = v0[1] - v2[1], bz = v0[2] - v2[2];
+            float rec[16] = {v0[0], v0[1], v0[2], fbits(tri_index[a]),
                              v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f,
-                             v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f};
-            out_tris.insert(out_tris.end(), rec, rec + 12);
+                             v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f,
+                             std::fmaf(ay, bz, -(az * by)), std::fmaf(az, bx, -(ax * bz)), std::fmaf(ax, by, -(ay * bx)), 0.f};
+            out_tris.insert(out_tris.end(), rec, rec + 16);
             count++;
         }
         if (count == 0) {  // empty leaf: one degenerate record that can never be hit
-            float rec[12] = {0, 0, 0, fbits(-1), 0, 0, 0, 0, 0, 0, 0, 0};
-            out_tris.insert(out_tris.end(), rec, rec + 12);
+            float rec[16] = {0, 0, 0, fbits(-1), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            out_tris.insert(out_tris.end(), rec, rec + 16);
             count = 1;
         }
-        out_tris[out_tris.size() - 12 + 7] = fbits(1);  // e1.w of the last record
+        out_tris[out_tris.size() - 16 + 7] = fbits(1);  // e1.w of the last record
         n_leaves++;
         n_refs += count;
-        out_link = ~(int32_t)first;
+        out_link = ~(int32_t)(first + tri_base);  // records follow the nodes in the one item buffer
         return true;
     };
 
@@ -355,13 +386,15 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
-    (void)hipFree(c->d_tris); c->d_tris = nullptr;
+    c->d_tris = nullptr;
     c->has_bvh = false;
+    if (n_out * 4 != tri_base) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: internal node count mismatch");
     const size_t nb = out_nodes.size() * sizeof(float), tb = out_tris.size() * sizeof(float);
-    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb));
-    HIP_TRY(c, hipMalloc((void**)&c->d_tris, tb));
+    if ((nb + tb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
+    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb));
+    c->d_tris = c->d_nodes;  // one item buffer: links index it directly
     HIP_TRY(c, hipMemcpy(c->d_nodes, out_nodes.data(), nb, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_tris, out_tris.data(), tb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, out_tris.data(), tb, hipMemcpyHostToDevice));
     c->n_inner = n_out;
     c->n_refs = n_refs;
     c->n_leaves = n_leaves;
@@ -452,7 +485,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    const bool persistent = c->opt_kernel == PT_KERNEL_PERSISTENT;
+    const bool persistent = c->opt_kernel == PT_KERNEL_PERSISTENT || c->opt_kernel == PT_KERNEL_AUTO;
     const int need = stack_for_depth(c->has_bvh ? c->max_depth : 0);
     (void)need;  // any depth <= 64 works with every LDS window: deeper entries overflow
     int lstk = c->opt_lstk ? c->opt_lstk : PT_STACK_CAP;
@@ -471,38 +504,42 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     const int work_blocks = (P.n_tiles * 64 + PT_CHUNK * (PT_BLOCK / 64) - 1) / (PT_CHUNK * (PT_BLOCK / 64));
     // persistent grid: as many blocks as can be resident (no grid-wide wait anywhere, so an
     // over-estimate only means a few late blocks find the queue empty and exit)
-#define PT_LAUNCH(COUNT, OCC, LSTK)                                                                              \
+#define PT_LAUNCH(COUNT, OCC, LSTK, ALG)                                                                         \
     do {                                                                                                         \
         if (persistent) {                                                                                        \
             int per_cu = 0;                                                                                      \
-            HIP_TRY(c, allow_lds(k_trace_persist_bvh2<COUNT, OCC, LSTK>, lds));                                  \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persist_bvh2<COUNT, OCC, LSTK>,    \
+            HIP_TRY(c, allow_lds(k_trace_persist_bvh2<COUNT, OCC, LSTK, ALG>, lds));                             \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_persist_bvh2<COUNT, OCC, LSTK, ALG>, \
                                                              PT_BLOCK, lds) != hipSuccess || per_cu < 1)        \
                 per_cu = 1;                                                                                      \
-            hipLaunchKernelGGL((k_trace_persist_bvh2<COUNT, OCC, LSTK>),                                         \
+            hipLaunchKernelGGL((k_trace_persist_bvh2<COUNT, OCC, LSTK, ALG>),                                    \
                                dim3(std::min(per_cu * c->n_cu, std::max(1, work_blocks))), dim3(PT_BLOCK), lds,  \
                                c->stream, P);                                                                    \
         } else {                                                                                                 \
-            HIP_TRY(c, allow_lds(k_trace_mega_bvh2<COUNT, OCC, LSTK>, lds));                                     \
-            hipLaunchKernelGGL((k_trace_mega_bvh2<COUNT, OCC, LSTK>), dim3(blocks), dim3(PT_BLOCK), lds,         \
+            HIP_TRY(c, allow_lds(k_trace_mega_bvh2<COUNT, OCC, LSTK, ALG>, lds));                                \
+            hipLaunchKernelGGL((k_trace_mega_bvh2<COUNT, OCC, LSTK, ALG>), dim3(blocks), dim3(PT_BLOCK), lds,    \
                                c->stream, P);                                                                    \
         }                                                                                                        \
     } while (0)
-#define PT_LAUNCH_OCC(COUNT, LSTK)                       \
-    do {                                                 \
-        if (c->opt_occ == 8) PT_LAUNCH(COUNT, 8, LSTK);  \
-        else if (c->opt_occ == 6) PT_LAUNCH(COUNT, 6, LSTK); \
-        else PT_LAUNCH(COUNT, 4, LSTK);                  \
+#define PT_LAUNCH_ALG(COUNT, OCC, LSTK)                   \
+    do {                                                  \
+        if (c->opt_walk == 1) PT_LAUNCH(COUNT, OCC, LSTK, 1); \
+        else PT_LAUNCH(COUNT, OCC, LSTK, 0);              \
+    } while (0)
+#define PT_LAUNCH_OCC(COUNT, LSTK)                            \
+    do {                                                      \
+        if (c->opt_occ == 8) PT_LAUNCH_ALG(COUNT, 8, LSTK);   \
+        else if (c->opt_occ == 6) PT_LAUNCH_ALG(COUNT, 6, LSTK); \
+        else PT_LAUNCH_ALG(COUNT, 4, LSTK);                   \
     } while (0)
     if (c->opt_counters) {
         if (lstk == 16) PT_LAUNCH_OCC(true, 16);
-        else if (lstk == 32) PT_LAUNCH_OCC(true, 32);
         else PT_LAUNCH_OCC(true, PT_STACK_CAP);
     } else {
         if (lstk == 16) PT_LAUNCH_OCC(false, 16);
-        else if (lstk == 32) PT_LAUNCH_OCC(false, 32);
         else PT_LAUNCH_OCC(false, PT_STACK_CAP);
     }
+#undef PT_LAUNCH_ALG
 #undef PT_LAUNCH_OCC
 #undef PT_LAUNCH
     HIP_TRY(c, hipGetLastError());

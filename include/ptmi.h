@@ -64,11 +64,11 @@ enum {
 
 /* pt_ctx kernel selection (pt_set_option PT_OPT_KERNEL) */
 enum {
-    PT_KERNEL_AUTO = 0,      /* best validated variant for the uploaded scene           */
-    PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, binary tree, bit-exact vs oracle    */
-    PT_KERNEL_MEGA_WIDE = 2, /* one lane per pixel, 4-wide 128-byte nodes                */
-    PT_KERNEL_PERSISTENT = 3,/* persistent waves, tile queue, lane refill               */
-    PT_KERNEL_WAVEFRONT = 4  /* stage-split: generate / extend / shade with compaction   */
+    PT_KERNEL_AUTO = 0,      /* fastest validated variant (currently PT_KERNEL_PERSISTENT)       */
+    PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, one wave per 8x8 tile, bounce by bounce      */
+    PT_KERNEL_MEGA_WIDE = 2, /* reserved: wide compressed nodes (not in this build)              */
+    PT_KERNEL_PERSISTENT = 3,/* persistent waves: work queue, ballot/prefix-count lane refill    */
+    PT_KERNEL_WAVEFRONT = 4  /* reserved: stage-split generate / extend / shade (not in build)   */
 };
 
 enum {
@@ -76,11 +76,13 @@ enum {
     PT_OPT_COUNTERS = 2,      /* 1 = instrumented launch: fill pt_counters (slower)         */
     PT_OPT_TIMING = 3,        /* 1 = bracket every launch with hipEvents (pt_last_kernel_ms) */
     PT_OPT_BATCH = 4,         /* persistent kernel: waiting lanes (1..64) that make a wave
-                                 leave the traversal loop to shade / refill; default 16      */
+                                 leave the traversal loop to shade / refill; default 32      */
     PT_OPT_TOP_NODES = 5,     /* BVH nodes (breadth-first prefix, 0..1024) mirrored in LDS    */
     PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the kernel's registers are budgeted for: 4/6/8 */
-    PT_OPT_LDS_STACK = 7      /* traversal-stack entries kept in LDS per lane: 16 (default), 32,
-                                 or 0 = all 72; deeper entries overflow to private memory     */
+    PT_OPT_LDS_STACK = 7,     /* traversal-stack entries kept in LDS per lane: 16 (default) or
+                                 0 = all 72; deeper entries overflow to private memory        */
+    PT_OPT_WALK = 8           /* closest-hit walk: 0 = while-while (Aila-Laine order, as the
+                                 reference), 1 = unified-step (default; same hits)            */
 };
 
 /* CamInfo, GpuPathTracer/CpuStructs.hpp:19-28 (pitch/yaw/dirty/bias/enabled are host-only

@@ -15,8 +15,8 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--mat", type=int, default=0)
 ap.add_argument("--no-spheres", action="store_true")
-ap.add_argument("--variants", default="mega::0:4:32,mega::64:4:32,mega::0:6:32,mega::0:6:16,mega::64:6:16,mega::0:8:16,mega::64:8:16,persist:16:0:6:16,persist:16:0:8:16",
-                help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack]]]]")
+ap.add_argument("--variants", default="mega::64:8:16:0,mega::0:8:16:1,mega::0:6:16:1,mega::0:4:16:1,persist:16:0:8:16:1,persist:16:0:6:16:1,persist:16:0:4:16:1,persist:8:0:8:16:1,persist:32:0:8:16:1,persist:16:64:8:16:0",
+                help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack[:walk]]]]]")
 a = ap.parse_args()
 
 W, H = a.width, a.height
@@ -28,18 +28,19 @@ cam = g.default_camera(W, H)
 acc, rgba = pt.alloc_frame(W, H)
 variants = []
 for v in a.variants.split(","):
-    parts = v.split(":") + ["", "", "", ""]
+    parts = v.split(":") + ["", "", "", "", ""]
     variants.append((v, {"mega": g.KERNEL_MEGA_BVH2, "persist": g.KERNEL_PERSISTENT, "wide": g.KERNEL_MEGA_WIDE}[parts[0]],
                      int(parts[1]) if parts[1] else 16, int(parts[2]) if parts[2] else 64,
-                     int(parts[3]) if parts[3] else 4, int(parts[4]) if parts[4] else 0))
+                     int(parts[3]) if parts[3] else 8, int(parts[4]) if parts[4] else 16, int(parts[5]) if parts[5] else 1))
 res = {v[0]: [] for v in variants}
 for r in range(a.rounds + 1):
-    for name, k, batch, top, occ, lstk in variants:
+    for name, k, batch, top, occ, lstk, walk in variants:
         pt.set_option(g.OPT_KERNEL, k)
         pt.set_option(g.OPT_BATCH, batch)
         pt.set_option(g.OPT_TOP_NODES, top)
         pt.set_option(g.OPT_OCCUPANCY, occ)
         pt.set_option(g.OPT_LDS_STACK, lstk)
+        pt.set_option(g.OPT_WALK, walk)
         pt.sync()
         t0 = time.perf_counter()
         for f in range(a.frames):
@@ -54,4 +55,4 @@ for r in range(a.rounds + 1):
 print(f"scene {a.scene} {W}x{H} mat {a.mat} spheres {not a.no_spheres}: ms/frame (median, min) and Mrays/s at median (closed-scene bound)")
 for name, v in res.items():
     med, mn = float(np.median(v)), float(np.min(v))
-    print(f"  {name:22s} median {med:7.3f} ms  min {mn:7.3f} ms   {W * H * 4 / med / 1e3:8.1f} Mrays/s")
+    print(f"  {name:26s} median {med:7.3f} ms  min {mn:7.3f} ms   {W * H * 4 / med / 1e3:8.1f} Mrays/s")

@@ -1,0 +1,100 @@
+// ubench_gather.hip — micro-benchmark behind DESIGN.md §5: how fast can a CU gather random
+// 64-byte items (BVH nodes / triangle records) that sit in L2 / Infinity Cache, as a function
+// of HOW the 64 bytes are requested?
+//   mode 0: every lane loads its own item with 4 x global_load_dwordx4 (what a per-lane BVH
+//           walk does: 64 different cache lines per wave instruction)
+//   mode 1: quad-cooperative: the 4 lanes of a quad load the 4 consecutive 16-byte pieces of ONE
+//           lane's item per instruction (4 instructions serve the quad's 4 items), data is
+//           handed to the owner with DPP quad_perm moves
+//   mode 2: as mode 0 but 2 x dwordx4 (32-byte items: a compressed node)
+// Dependent chain: the next index depends on the loaded data, like pointer chasing.
+// Build: hipcc --offload-arch=gfx950 -O3 -o ubench_gather tools/ubench_gather.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+template <int SEL>
+__device__ __forceinline__ float quad_bcast(float v) {
+    // v_mov_b32 dpp quad_perm:[SEL,SEL,SEL,SEL]
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), SEL * 0x55, 0xf, 0xf, true));
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ items, uint32_t n_items, int iters, float* out) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ql = threadIdx.x & 3;
+    uint32_t idx = mix(gid * 2654435761u + 12345u) % n_items;
+    float acc = 0.f;
+    for (int it = 0; it < iters; it++) {
+        float4 q0, q1, q2, q3;
+        if (MODE == 0) {
+            const float4* p = items + (size_t)idx * 4;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        } else if (MODE == 2) {
+            const float4* p = items + (size_t)idx * 4;
+            q0 = p[0]; q1 = p[1]; q2 = q0; q3 = q1;
+        } else {
+            // owner k's index broadcast to the quad, each lane fetches piece `ql` of that item
+            const uint32_t i0 = __builtin_amdgcn_mov_dpp((int)idx, 0x00, 0xf, 0xf, true);
+            const uint32_t i1 = __builtin_amdgcn_mov_dpp((int)idx, 0x55, 0xf, 0xf, true);
+            const uint32_t i2 = __builtin_amdgcn_mov_dpp((int)idx, 0xAA, 0xf, 0xf, true);
+            const uint32_t i3 = __builtin_amdgcn_mov_dpp((int)idx, 0xFF, 0xf, 0xf, true);
+            const float4 r0 = items[(size_t)i0 * 4 + ql];
+            const float4 r1 = items[(size_t)i1 * 4 + ql];
+            const float4 r2 = items[(size_t)i2 * 4 + ql];
+            const float4 r3 = items[(size_t)i3 * 4 + ql];
+            // owner ql needs piece c (from lane c) of register set r_ql: select the set, then 4 bcasts per piece
+            const float4 mine = ql == 0 ? r0 : (ql == 1 ? r1 : (ql == 2 ? r2 : r3));
+            (void)mine;
+            // full hand-off: for each piece c, each dword: pick from lane c the register set of the DEST lane.
+            // dest-dependent register choice = 4 bcasts + 3 selects per dword
+#define HAND(c, comp)                                                                                        \
+    (ql == 0 ? quad_bcast<c>(r0.comp) : (ql == 1 ? quad_bcast<c>(r1.comp) : (ql == 2 ? quad_bcast<c>(r2.comp) : quad_bcast<c>(r3.comp))))
+            q0 = make_float4(HAND(0, x), HAND(0, y), HAND(0, z), HAND(0, w));
+            q1 = make_float4(HAND(1, x), HAND(1, y), HAND(1, z), HAND(1, w));
+            q2 = make_float4(HAND(2, x), HAND(2, y), HAND(2, z), HAND(2, w));
+            q3 = make_float4(HAND(3, x), HAND(3, y), HAND(3, z), HAND(3, w));
+#undef HAND
+        }
+        const float s = q0.x + q0.y + q0.z + q0.w + q1.x + q1.y + q1.z + q1.w + q2.x + q2.y + q2.z + q2.w + q3.x + q3.y + q3.z + q3.w;
+        acc += s;
+        idx = mix(idx ^ __float_as_uint(q3.w) ^ (uint32_t)it) % n_items;
+    }
+    out[gid] = acc;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t n_items = argc > 1 ? (uint32_t)atoi(argv[1]) : 1000000u;  // 64 MB
+    const int iters = argc > 2 ? atoi(argv[2]) : 256;
+    const int blocks = 256 * 8, threads = 256;
+    std::vector<float> h((size_t)n_items * 16);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) * 1e-3f;
+    float4* d_items; float* d_out;
+    hipMalloc(&d_items, h.size() * 4);
+    hipMalloc(&d_out, (size_t)blocks * threads * 4);
+    hipMemcpy(d_items, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int mode = 0; mode < 3; mode++) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; rep++) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 1) hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double items_n = (double)blocks * threads * iters;
+        const double bytes = items_n * (mode == 2 ? 32 : 64);
+        printf("mode %d: %.3f ms  %.1f Gitems/s  %.1f GB/s chip  %.1f GB/s per CU\n", mode, best, items_n / best / 1e6,
+               bytes / best / 1e6, bytes / best / 1e6 / 256);
+    }
+    return 0;
+}
