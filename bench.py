@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu-reference", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the metal/spec side measurements")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N>1 dry run on a ONE-GPU box: every rank uses cuda:0, gloo backend, stripes gathered "
+                         "through host memory (validates the multi-rank code path, not its speed)")
     return ap.parse_args()
 
 
@@ -127,11 +130,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the path tracer has no CPU fallback)")
+    if a.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H = a.width, a.height
     mat = {"diff": g.MAT_DIFF, "metal": g.MAT_METAL, "spec": g.MAT_SPEC, "refr": g.MAT_REFR}[a.mat]
@@ -142,7 +150,6 @@ def main():
     cam = g.default_camera(W, H)
     base = g.default_params(W, H, depth=a.depth, tri_mat=mat)
     base.flags = g.FLAG_WRITE_RGBA
-    base.part_index, base.part_count, base.part_rows = rank, world, a.stripe_rows
 
     pt = g.PathTracer(local_rank)
     # one explicit HIP stream shared by torch (events, copies, RCCL ordering) and the kernels:
@@ -164,28 +171,52 @@ def main():
     info = pt.scene_info()
 
     # full-frame buffers, height padded so that the stripes split evenly over the ranks
+    from gpu_pathtracer_amd import tile_split
+    layout = tile_split.StripeLayout(W, H, world, rank, a.stripe_rows)
     rows = a.stripe_rows
-    n_stripes = -(-H // rows)
-    n_stripes_pad = -(-n_stripes // world) * world
-    Hp = n_stripes_pad * rows
-    accum = torch.zeros((Hp, W, 3), dtype=torch.float32, device=dev)
-    rgba = torch.zeros((Hp, W), dtype=torch.int32, device=dev)
-    own = rgba.view(n_stripes_pad // world, world, rows * W)[:, rank, :]   # this rank's stripes (strided view)
-    if world > 1:
-        send = torch.empty((n_stripes_pad // world, rows * W), dtype=torch.int32, device=dev)
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-        frame_view = rgba.view(n_stripes_pad // world, world, rows * W)
+    layout.apply(base)
+    accum = torch.zeros((layout.padded_height, W, 3), dtype=torch.float32, device=dev)
+    # display words are double-buffered so that the gather of frame i (side stream, RCCL)
+    # overlaps the render of frame i+1 (main stream); PT_BENCH_NO_OVERLAP=1 serialises them
+    overlap = world > 1 and not a.rehearse and os.environ.get("PT_BENCH_NO_OVERLAP", "0") != "1"
+    n_buf = 2 if overlap else 1
+    rgbas = [torch.zeros((layout.padded_height, W), dtype=torch.int32, device=dev) for _ in range(n_buf)]
+    rgba = rgbas[0]
+    staging = [None] * n_buf
+    side = torch.cuda.Stream(device=dev) if overlap else None
+    ev_render = [torch.cuda.Event() for _ in range(n_buf)]
+    ev_gather = [None] * n_buf
+    step_no = [0]
 
-    def step(i, params=base, spp=a.spp):
+    def step(i, params=base, spp=a.spp, fresh=False):
         p = g.Params.from_buffer_copy(params)
-        p.frame, p.sample_index = i * spp, 1 + i * spp
-        pt.launch_kernel(accum.data_ptr(), rgba.data_ptr(), cam, p, spp)
-        if world > 1:
-            send.copy_(own)
-            dist.gather(send, recv, dst=0)
+        p.frame, p.sample_index = i * spp, 1 if fresh else 1 + i * spp
+        k = step_no[0] % n_buf
+        step_no[0] += 1
+        buf = rgbas[k]
+        if overlap and ev_gather[k] is not None:
+            stream.wait_event(ev_gather[k])          # the gather that last read this buffer is done
+        pt.launch_kernel(accum.data_ptr(), buf.data_ptr(), cam, p, spp)
+        if world == 1:
+            return
+        if overlap:
+            ev_render[k].record(stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_render[k])
+                staging[k] = tile_split.gather_stripes(buf, layout, dst=0, staging=staging[k])
+                ev_gather[k] = torch.cuda.Event()
+                ev_gather[k].record(side)
+                buf.record_stream(side)
+        elif not a.rehearse:   # display words of the finished stripes -> rank 0 (RCCL over xGMI)
+            staging[k] = tile_split.gather_stripes(buf, layout, dst=0, staging=staging[k])
+        else:
+            host = buf.cpu()
+            staging[k] = tile_split.gather_stripes(host, layout, dst=0, staging=staging[k])
             if rank == 0:
-                for r in range(1, world):
-                    frame_view[:, r, :].copy_(recv[r])
+                buf.copy_(host)
+
+    def last_frame():
+        return rgbas[(step_no[0] - 1) % n_buf]
 
     def barrier():
         if world > 1:
@@ -207,7 +238,7 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         kms = [e0.elapsed_time(e1) for e0, e1 in ev] if ev else None
@@ -219,7 +250,7 @@ def main():
 
     # exact segment count of the timed frames: replay them instrumented (untimed)
     pt.set_option(g.OPT_COUNTERS, 1)
-    seg = torch.zeros(2, dtype=torch.float64, device=dev)
+    seg = torch.zeros(2, dtype=torch.float64, device="cpu" if a.rehearse else dev)
     n_count = min(a.steps, 4)
     for k in range(n_count):
         step(a.warmup + k)
@@ -246,25 +277,42 @@ def main():
             dtx, _ = timed(n_x, 1, pm)
             extra[f"mrays_per_s_{name}"] = round(W * H * a.depth * a.spp * n_x / dtx / 1e6, 1)
 
+    merged_ok = None
+    if world > 1:
+        # rank 0 re-renders the last gathered frame alone and compares the display words
+        last = a.warmup + a.steps
+        step(last, fresh=True)   # sample_index 1: the frame does not depend on accumulated history
+        torch.cuda.synchronize()
+        if rank == 0:
+            solo = g.Params.from_buffer_copy(base)
+            solo.part_index, solo.part_count = 0, 1
+            solo.frame, solo.sample_index = last * a.spp, 1
+            acc2 = torch.zeros_like(accum)
+            rgba2 = torch.zeros_like(rgba)
+            pt.launch_kernel(acc2.data_ptr(), rgba2.data_ptr(), cam, solo, a.spp)
+            torch.cuda.synchronize()
+            merged_ok = bool(torch.equal(last_frame()[:H], rgba2[:H]))
     if rank == 0:
         value = total_rays / dt / 1e6
         out = {
             "metric": "Mrays/sec, cornell_dragon 1920x1080 (+ achieved algorithmic GB/s vs HBM roofline)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if a.rehearse else ""),
             "config": {"workload": f"{a.scene} ({mesh.n_tris} tris) {W}x{H} depth {a.depth} {a.mat} + "
                                    f"{'reference 8-sphere room' if n_sph else 'no spheres'}, {a.spp} spp per step",
                        "bvh": {"inner": info["n_inner"], "tri_refs": info["n_tri_refs"], "max_depth": info["max_depth"],
                                "device_mb": round(info["device_bytes"] / 2 ** 20, 1)},
-                       "parallelism": f"tile-split x{world} ({rows}-row stripes, RCCL gather of RGBA8 per step)" if world > 1 else "1 GPU",
-                       "closed_scene": bool(closed), "rays_per_step": rays_per_step},
+                       "parallelism": (f"tile-split x{world} ({rows}-row stripes, RCCL all-gather of RGBA8 every step"
+                                       f"{', overlapped with the next render' if overlap else ''})") if world > 1 else "1 GPU",
+                       "closed_scene": bool(closed), "rays_per_step": rays_per_step,
+                       "tile_split_equals_single_gpu": merged_ok},
         }
         out.update(extra)
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if world == 1:
             kavg = float(np.mean(kernel_ms))
-            roof["kernel"] = "k_trace_mega_bvh2"
+            roof["kernel"] = "k_trace_persist_bvh2" if a.kernel in (0, 3) else "k_trace_mega_bvh2"
             roof["kernel_ms_avg"] = round(kavg, 4)
             if a.cpu_frames > 0:
                 cb, cnt, _ = cpu_baseline(g, bvh, sph, cam, base, a.warmup * a.spp, a.cpu_frames, a.spp)
