@@ -248,10 +248,17 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
         const float4 q0 = sc.nodes[a + 0];
         const float4 q1 = sc.nodes[a + 1];
         const float4 q2 = sc.nodes[a + 2];
-        const float4 q3 = sc.nodes[a + 3];
+        // 4th piece only for node lanes (links); a record's 4th piece (normal) is read on a hit.
+        // The CU's address/tag pipe costs ~1 cycle per LANE-level 16-byte load.
+        int cx = 0, cy = 0;
+        if (cur >= 0) {
+            const float4 q3 = sc.nodes[a + 3];
+            cx = __float_as_int(q3.x);
+            cy = __float_as_int(q3.y);
+        }
+        asm volatile("" : "+v"(cx), "+v"(cy));
         if (cur >= 0) {
             if (COUNT) tc.inner++;
-            int cx = __float_as_int(q3.x), cy = __float_as_int(q3.y);
             const float c0lox = fmaf(q0.x, idx, -oodx), c0hix = fmaf(q0.y, idx, -oodx);
             const float c0loy = fmaf(q0.z, idy, -oody), c0hiy = fmaf(q0.w, idy, -oody);
             const float c1lox = fmaf(q1.x, idx, -oodx), c1hix = fmaf(q1.y, idx, -oodx);
@@ -284,6 +291,7 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
             if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                 h.t = t;
                 h.tri = id;
+                const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
                 h.n = V3(q3.x, q3.y, q3.z);
             }
             if (__float_as_int(q1.w) != 0) {  // last record of the leaf

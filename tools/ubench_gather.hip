@@ -39,6 +39,21 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ it
         } else if (MODE == 2) {
             const float4* p = items + (size_t)idx * 4;
             q0 = p[0]; q1 = p[1]; q2 = q0; q3 = q1;
+        } else if (MODE == 3) {  // 16-byte items: one dwordx4
+            const float4* p = items + (size_t)idx * 4;
+            q0 = p[0]; q1 = q0; q2 = q0; q3 = q0;
+        } else if (MODE == 4) {  // 32 bytes as 4 x dwordx2
+            const float2* p = (const float2*)(items + (size_t)idx * 4);
+            const float2 a = p[0], b = p[1], c = p[2], d = p[3];
+            q0 = make_float4(a.x, a.y, b.x, b.y); q1 = make_float4(c.x, c.y, d.x, d.y); q2 = q0; q3 = q1;
+        } else if (MODE == 5) {  // 48 bytes: 3 x dwordx4
+            const float4* p = items + (size_t)idx * 4;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = q2;
+        } else if (MODE == 6) {  // 128 bytes: 8 x dwordx4 (two consecutive items)
+            const float4* p = items + (size_t)(idx & ~1u) * 4;
+            const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g2 = p[6], h = p[7];
+            q0 = make_float4(a.x + e.x, a.y + e.y, a.z + e.z, a.w + e.w); q1 = make_float4(b.x + f.x, b.y + f.y, b.z + f.z, b.w + f.w);
+            q2 = make_float4(c.x + g2.x, c.y + g2.y, c.z + g2.z, c.w + g2.w); q3 = make_float4(d.x + h.x, d.y + h.y, d.z + h.z, d.w + h.w);
         } else {
             // owner k's index broadcast to the quad, each lane fetches piece `ql` of that item
             const uint32_t i0 = __builtin_amdgcn_mov_dpp((int)idx, 0x00, 0xf, 0xf, true);
@@ -80,19 +95,24 @@ int main(int argc, char** argv) {
     hipMalloc(&d_out, (size_t)blocks * threads * 4);
     hipMemcpy(d_items, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 7; mode++) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 1) hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
-            else hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 2) hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 3) hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 4) hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 5) hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep > 0 && ms < best) best = ms;
         }
         const double items_n = (double)blocks * threads * iters;
-        const double bytes = items_n * (mode == 2 ? 32 : 64);
+        static const int bytes_of[7] = {64, 64, 32, 16, 32, 48, 128};
+        const double bytes = items_n * bytes_of[mode];
         printf("mode %d: %.3f ms  %.1f Gitems/s  %.1f GB/s chip  %.1f GB/s per CU\n", mode, best, items_n / best / 1e6,
                bytes / best / 1e6, bytes / best / 1e6 / 256);
     }
