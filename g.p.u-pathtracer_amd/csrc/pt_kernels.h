@@ -25,8 +25,10 @@ struct KScene {
     const pt_sphere_d* __restrict__ spheres;
     int n_spheres;
     int has_bvh;
-    int n_top;     // nodes [0, n_top) (breadth-first prefix of the tree) are mirrored in LDS
+    int n_top;     // nodes [top_base/4, top_base/4 + n_top) (breadth-first prefix) are mirrored in LDS
     int stack_n;   // LDS stack entries per lane
+    int top_base;  // float4 index of the mirrored tree's root: 0 (binary) or wide_root
+    int wide_root; // float4 index of the 4-wide quantised tree's root (pt_wide.h), 0 if absent
 };
 
 struct KParams {
@@ -119,7 +121,7 @@ struct TravStack {
 };
 
 template <class STK>
-__device__ __forceinline__ void trav_begin(TravState& s, v3 o, v3 d, STK& stk) {
+__device__ __forceinline__ void trav_begin(TravState& s, v3 o, v3 d, STK& stk, int root = 0) {
     const float ooeps = 8.271806125530277e-25f;  // exp2f(-80), cudaUtils.h:283
     s.idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
     s.idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
@@ -127,7 +129,7 @@ __device__ __forceinline__ void trav_begin(TravState& s, v3 o, v3 d, STK& stk) {
     s.oodx = o.x * s.idx; s.oody = o.y * s.idy; s.oodz = o.z * s.idz;
     s.sp = 0;
     stk.put(0, PT_SENTINEL);
-    s.leaf = 0; s.node = 0;
+    s.leaf = 0; s.node = root;
     s.h.t = PT_F32_MAX; s.h.tri = -1; s.h.n = V3(0.f, 0.f, 0.f);
 }
 
@@ -311,6 +313,110 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
     return cur == PT_SENTINEL;
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide walk: unified-step over the 4-wide quantised tree of pt_wide.h.  A node item tests four
+// child boxes (24 v_cvt_f32_ubyte + 24 v_fma + min/max), sorts the hit children by entry
+// distance with a 5-exchange network on (distance bits | child number) keys, continues with the
+// nearest and pushes the rest far-to-near.  Record items are the exact Moller-Trumbore test of
+// the other walks, so a reported hit is bit-identical to theirs; only the set of candidates the
+// (outward-rounded) boxes let through differs.  3 pieces for a record, 4 for a node.
+template <bool COUNT, bool DYN, bool TOP, class STK>
+__device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                              TravCount& tc, int n_dead, int batch) {
+    int cur = s.node, sp = s.sp;
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    while (cur != PT_SENTINEL) {
+        const int a = cur >= 0 ? cur : ~cur;
+        float4 q0, q1, q2;
+        int l2 = 0, l3 = 0;
+        const int ti = a - sc.top_base;
+        if (TOP && cur >= 0 && (unsigned)ti < (unsigned)(sc.n_top * 4)) {
+            const int i = ti >> 2;
+            q0 = s_dyn[i];
+            q1 = s_dyn[sc.n_top + i];
+            q2 = s_dyn[2 * sc.n_top + i];
+            const float4 q3 = s_dyn[3 * sc.n_top + i];
+            l2 = __float_as_int(q3.x);
+            l3 = __float_as_int(q3.y);
+            asm volatile("" : "+v"(q0.x), "+v"(l2));
+        } else {
+            q0 = sc.nodes[a + 0];
+            q1 = sc.nodes[a + 1];
+            q2 = sc.nodes[a + 2];
+            if (cur >= 0) {
+                const float4 q3 = sc.nodes[a + 3];
+                l2 = __float_as_int(q3.x);
+                l3 = __float_as_int(q3.y);
+            }
+            asm volatile("" : "+v"(l2), "+v"(l3));
+        }
+        if (cur >= 0) {
+            if (COUNT) tc.inner++;
+            const uint32_t meta = __float_as_uint(q0.w);
+            const float sx = __uint_as_float((meta & 0xffu) << 23) * idx;
+            const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy;
+            const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+            const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
+            const int nch = (int)(meta >> 24);
+            const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
+            const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
+            const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
+            uint32_t key[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float lx = fmaf((float)((qlx >> (8 * k)) & 0xffu), sx, bx), hx = fmaf((float)((qhx >> (8 * k)) & 0xffu), sx, bx);
+                const float ly = fmaf((float)((qly >> (8 * k)) & 0xffu), sy, by), hy = fmaf((float)((qhy >> (8 * k)) & 0xffu), sy, by);
+                const float lz = fmaf((float)((qlz >> (8 * k)) & 0xffu), sz, bz), hz = fmaf((float)((qhz >> (8 * k)) & 0xffu), sz, bz);
+                const float tmin = fmaxf(fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz)), 0.0f);
+                const float tmax = fminf(fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz)), h.t);
+                const bool hit = (k < nch) && (tmin <= tmax);
+                key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
+            }
+            // sorting network for 4 keys: (0,1)(2,3)(0,2)(1,3)(1,2)
+#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+#define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
+            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
+            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
+            if (key[1] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[1])); }
+            if (key[0] != 0xffffffffu) {
+                cur = PT_LINK(key[0]);
+            } else {
+                cur = stk.get(sp);
+                sp--;
+            }
+#undef PT_LINK
+            if (COUNT && cur < 0) tc.leaves++;
+        } else {
+            if (COUNT) tc.tris++;
+            const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+            const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+            const int id = __float_as_int(q0.w);
+            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                h.t = t;
+                h.tri = id;
+                const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
+                h.n = V3(q3.x, q3.y, q3.z);
+            }
+            if (__float_as_int(q1.w) != 0) {  // last record of the leaf
+                cur = stk.get(sp);
+                sp--;
+                if (COUNT && cur < 0 && cur != PT_SENTINEL) tc.leaves++;
+            } else {
+                cur -= 4;  // ~(a + 4)
+            }
+        }
+        if (DYN) {  // enough lanes are waiting for service: hand the wave back
+            const int active = __popcll(__ballot(cur != PT_SENTINEL));
+            if (64 - active - n_dead >= batch) break;
+        }
+    }
+    s.node = cur; s.sp = sp; s.h = h;
+    return cur == PT_SENTINEL;
+}
+
 template <bool COUNT, bool TOP, class STK>
 __device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
                                          TravCount& tc, const float4* __restrict__ s_top) {
@@ -323,7 +429,7 @@ __device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull
 
 template <int BLOCK>
 __device__ __forceinline__ void lds_load_top(const KScene& sc, float4* __restrict__ s_top) {
-    for (int i = threadIdx.x; i < sc.n_top * 4; i += BLOCK) s_top[(i & 3) * sc.n_top + (i >> 2)] = sc.nodes[i];
+    for (int i = threadIdx.x; i < sc.n_top * 4; i += BLOCK) s_top[(i & 3) * sc.n_top + (i >> 2)] = sc.nodes[sc.top_base + i];
     __syncthreads();
 }
 
@@ -498,7 +604,12 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
         Hit h;
         h.t = PT_F32_MAX; h.tri = -1; h.n = V3(0.f, 0.f, 0.f);
         if (P.sc.has_bvh) {
-            if (ALG == 1) {
+            if (ALG == 2) {
+                TravState ts;
+                trav_begin(ts, ps.o, ps.d, stk, P.sc.wide_root);
+                trav_run_wide<COUNT, false, true, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
+                h = ts.h;
+            } else if (ALG == 1) {
                 TravState ts;
                 trav_begin(ts, ps.o, ps.d, stk);
                 trav_run_unified<COUNT, false, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
@@ -536,7 +647,7 @@ __device__ __forceinline__ bool pt_tile_coords(const KParams& P, int tile, int& 
 // trace<<<>>>, tracer.cu:343-400: one lane per pixel, one wave per 8x8 tile, `spp`
 // consecutive samples folded in registers.
 // OCC = waves per SIMD the register allocator must leave room for (4 / 6 / 8)
-// ALG = 0 while-while walk (Aila-Laine), 1 unified-step walk
+// ALG = 0 while-while walk (Aila-Laine), 1 unified-step walk, 2 wide (4-way quantised) walk
 template <bool COUNT, int OCC, int LSTK, int ALG>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams P) {
     float4* s_top = s_dyn;
@@ -695,7 +806,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                 phase = PH_SHADE;
                 ts.h.t = PT_F32_MAX; ts.h.tri = -1;
             } else if (P.sc.has_bvh) {
-                trav_begin(ts, ps.o, ps.d, stk);
+                trav_begin(ts, ps.o, ps.d, stk, ALG == 2 ? P.sc.wide_root : 0);
                 phase = PH_TRAV;
             } else {
                 ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.n = V3(0.f, 0.f, 0.f);
@@ -707,8 +818,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         {
             const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
             if (phase == PH_TRAV) {
-                const bool fin = (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
-                                            : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
+                const bool fin = (ALG == 2)   ? trav_run_wide<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                                 : (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                                              : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
                 if (fin) phase = PH_SHADE;
             }
         }
@@ -725,7 +837,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             }
             if (!done) {
                 if (P.sc.has_bvh) {
-                    trav_begin(ts, ps.o, ps.d, stk);
+                    trav_begin(ts, ps.o, ps.d, stk, ALG == 2 ? P.sc.wide_root : 0);
                     phase = PH_TRAV;
                 }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
             } else {

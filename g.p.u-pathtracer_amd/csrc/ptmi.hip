@@ -13,6 +13,7 @@
 
 #include "../../include/ptmi.h"
 #include "pt_kernels.h"
+#include "pt_scene_build.h"
 
 static_assert(sizeof(pt_sphere) == 44, "pt_sphere must match the reference Sphere (44 B)");
 static_assert(sizeof(pt_sphere_d) == sizeof(pt_sphere), "device sphere mirror");
@@ -35,6 +36,9 @@ struct pt_ctx {
     uint64_t n_inner = 0, n_refs = 0, n_leaves = 0, scene_bytes = 0;
     uint32_t max_depth = 0;
     uint32_t n_top_layout = 0;   // nodes [0, n_top_layout) are in breadth-first order
+    uint64_t wide_root = 0;      // float4 index of the 4-wide tree's root, 0 = not built
+    uint32_t wide_top_layout = 0, wide_depth = 0;
+    uint64_t n_wide = 0;
     bool has_bvh = false;
     // options
     int opt_kernel = PT_KERNEL_AUTO;
@@ -48,7 +52,8 @@ struct pt_ctx {
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
     int opt_occ = 8;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
-    int opt_walk = 1;            // 0 while-while, 1 unified-step (PT_OPT_WALK)
+    int opt_walk = 2;            // 0 while-while, 1 unified-step, 2 wide (PT_OPT_WALK)
+    int opt_leaf_max = 2;        // leaves with more references are split at upload (PT_OPT_LEAF_MAX)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 };
@@ -163,8 +168,12 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value != 4 && value != 6 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: occupancy must be 4, 6 or 8 waves per SIMD");
             c->opt_occ = value;
             return PT_OK;
+        case PT_OPT_LEAF_MAX:
+            if (value < 0 || value > 1024) return fail(c, PT_ERR_INVALID, "pt_set_option: leaf_max must be 0 (keep) .. 1024");
+            c->opt_leaf_max = value;   // takes effect at the next pt_upload_bvh
+            return PT_OK;
         case PT_OPT_WALK:
-            if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while) or 1 (unified-step)");
+            if (value < 0 || value > 2) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while), 1 (unified-step) or 2 (wide)");
             c->opt_walk = value;
             return PT_OK;
         case PT_OPT_LDS_STACK:
@@ -237,169 +246,39 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     if (n_node_vec4 * 16 >= (size_t)PT_SENTINEL || n_tri_vec4 >= (size_t)0x7fffffff)
         return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
 
-    const size_t n_nodes_in = n_node_vec4 / 4;
-    std::vector<int32_t> new_index(n_nodes_in, -1);  // old node number -> new node number
-    std::vector<float> out_nodes;
-    std::vector<float> out_tris;
-    out_nodes.reserve(n_node_vec4 * 4);
-    out_tris.reserve(n_tri_vec4 * 4);
-    uint64_t n_leaves = 0, n_refs = 0;
-    uint32_t max_depth = 0;
-
-    auto bits = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
-    auto fbits = [](int32_t i) { float f; std::memcpy(&f, &i, 4); return f; };
-
-    // count the reachable nodes first: the triangle records sit behind them in the same buffer
-    size_t tri_base = 0;
-    {
-        std::vector<size_t> st{0};
-        std::vector<uint8_t> mark(n_nodes_in, 0);
-        mark[0] = 1;
-        size_t n_reach = 0;
-        while (!st.empty()) {
-            const size_t u = st.back();
-            st.pop_back();
-            n_reach++;
-            for (int i = 0; i < 2; i++) {
-                const int32_t l = bits(nodes[16 * u + 12 + i]);
-                if (l < 0) continue;
-                if ((l % 64) != 0 || (size_t)l / 64 >= n_nodes_in)
-                    return fail(c, PT_ERR_INVALID, "pt_upload_bvh: child link is not a valid node byte offset");
-                if (mark[(size_t)l / 64]) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node referenced twice (not a tree)");
-                mark[(size_t)l / 64] = 1;
-                st.push_back((size_t)l / 64);
-            }
-        }
-        tri_base = n_reach * 4;  // float4 index of the first record
-    }
-    // emits one leaf, returns the link (~first float4 index) or 0 on error
-    auto emit_leaf = [&](int32_t link, int32_t& out_link) -> bool {
-        size_t a = (size_t)(~link);
-        const size_t first = out_tris.size() / 4;
-        size_t count = 0;
-        for (;; a += 3) {
-            if (a >= n_tri_vec4) return false;
-            const float* r = tri_verts + 4 * a;
-            uint32_t w0; std::memcpy(&w0, r, 4);
-            if (w0 == 0x80000000u) break;
-            if (a + 2 >= n_tri_vec4) return false;
-            const float* v0 = r; const float* v1 = r + 4; const float* v2 = r + 8;
-            // cross(v0-v1, v0-v2) with the kernels' vcross arithmetic (cudaUtils.h:432)
-            const float ax = v0[0] - v1[0], ay = v0[1] - v1[1], az = v0[2] - v1[2];
-            const float bx = v0[0] - v2[0], by = v0[1] - v2[1], bz = v0[2] - v2[2];
-            float rec[16] = {v0[0], v0[1], v0[2], fbits(tri_index[a]),
-                             v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.f,
-                             v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f,
-                             std::fmaf(ay, bz, -(az * by)), std::fmaf(az, bx, -(ax * bz)), std::fmaf(ax, by, -(ay * bx)), 0.f};
-            out_tris.insert(out_tris.end(), rec, rec + 16);
-            count++;
-        }
-        if (count == 0) {  // empty leaf: one degenerate record that can never be hit
-            float rec[16] = {0, 0, 0, fbits(-1), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            out_tris.insert(out_tris.end(), rec, rec + 16);
-            count = 1;
-        }
-        out_tris[out_tris.size() - 16 + 7] = fbits(1);  // e1.w of the last record
-        n_leaves++;
-        n_refs += count;
-        out_link = ~(int32_t)(first + tri_base);  // records follow the nodes in the one item buffer
-        return true;
-    };
-
-    // pass 1 (depth-first): validate links, emit leaves in tree order, record depths
-    std::vector<int32_t> leaf_link(2 * n_nodes_in, 0);
-    std::vector<uint32_t> depth(n_nodes_in, 0);
-    std::vector<uint8_t> seen(n_nodes_in, 0);
-    {
-        std::vector<size_t> stack{0};
-        seen[0] = 1;
-        while (!stack.empty()) {
-            const size_t u = stack.back();
-            stack.pop_back();
-            const float* src = nodes + 16 * u;
-            const int32_t link[2] = {bits(src[12]), bits(src[13])};
-            for (int i = 0; i < 2; i++) {
-                if (link[i] >= 0) {
-                    if ((link[i] % 64) != 0 || (size_t)link[i] / 64 >= n_nodes_in)
-                        return fail(c, PT_ERR_INVALID, "pt_upload_bvh: child link is not a valid node byte offset");
-                    const size_t child = (size_t)link[i] / 64;
-                    if (seen[child]) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: node referenced twice (not a tree)");
-                    seen[child] = 1;
-                    depth[child] = depth[u] + 1;
-                    if (depth[child] > 64) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: tree deeper than 64 (SplitBVHBuilder MaxDepth)");
-                } else {
-                    if (!emit_leaf(link[i], leaf_link[2 * u + i])) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: leaf runs past the triangle array");
-                    max_depth = std::max(max_depth, depth[u] + 1);
-                }
-            }
-            for (int i = 1; i >= 0; i--)  // child 0 is walked first
-                if (link[i] >= 0) stack.push_back((size_t)link[i] / 64);
-        }
-    }
-    // pass 2: new numbering = breadth-first for the top PT_MAX_TOP nodes (the LDS mirror is
-    // any prefix of it), depth-first below (a parent next to its first inner child)
-    std::vector<size_t> order;
-    order.reserve(n_nodes_in);
-    {
-        std::vector<size_t> frontier{0};
-        size_t head = 0;
-        while (head < frontier.size() && order.size() < (size_t)PT_MAX_TOP) {
-            const size_t u = frontier[head++];
-            new_index[u] = (int32_t)order.size();
-            order.push_back(u);
-            const float* src = nodes + 16 * u;
-            for (int i = 0; i < 2; i++) {
-                const int32_t l = bits(src[12 + i]);
-                if (l >= 0) frontier.push_back((size_t)l / 64);
-            }
-        }
-        const size_t n_bfs = order.size();
-        for (; head < frontier.size(); head++) {
-            std::vector<size_t> stack{frontier[head]};
-            while (!stack.empty()) {
-                const size_t u = stack.back();
-                stack.pop_back();
-                new_index[u] = (int32_t)order.size();
-                order.push_back(u);
-                const float* src = nodes + 16 * u;
-                for (int i = 1; i >= 0; i--) {
-                    const int32_t l = bits(src[12 + i]);
-                    if (l >= 0) stack.push_back((size_t)l / 64);
-                }
-            }
-        }
-        c->n_top_layout = (uint32_t)n_bfs;
-    }
-    const size_t n_out = order.size();
-    out_nodes.assign(n_out * 16, 0.f);
-    for (size_t k = 0; k < n_out; k++) {
-        const size_t u = order[k];
-        const float* src = nodes + 16 * u;
-        float* dst = &out_nodes[16 * k];
-        std::memcpy(dst, src, 12 * sizeof(float));
-        for (int i = 0; i < 2; i++) {
-            const int32_t l = bits(src[12 + i]);
-            dst[12 + i] = fbits(l >= 0 ? new_index[(size_t)l / 64] * 4 : leaf_link[2 * u + i]);  // float4 index | ~record
-        }
-    }
+    ptscene::Tree T;
+    std::string perr;
+    if (!ptscene::parse(nodes, n_node_vec4, tri_verts, n_tri_vec4, tri_index, T, perr))
+        return fail(c, PT_ERR_INVALID, "pt_upload_bvh: " + perr);
+    ptscene::refine(T, (uint32_t)c->opt_leaf_max);
+    ptscene::Output O;
+    ptscene::emit(T, PT_MAX_TOP, O);
+    const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
+    if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
     c->d_tris = nullptr;
     c->has_bvh = false;
-    if (n_out * 4 != tri_base) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: internal node count mismatch");
-    const size_t nb = out_nodes.size() * sizeof(float), tb = out_tris.size() * sizeof(float);
-    if ((nb + tb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
-    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb));
+    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb + wb));
     c->d_tris = c->d_nodes;  // one item buffer: links index it directly
-    HIP_TRY(c, hipMemcpy(c->d_nodes, out_nodes.data(), nb, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, out_tris.data(), tb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
+    c->wide_root = O.wide_root_f4;
+    c->wide_top_layout = O.n_top_wide;
+    c->wide_depth = O.depth_wide;
+    c->n_wide = O.wide.size() / 16;
+    c->n_top_layout = O.n_top_bin;
+    const size_t n_out = O.bin.size() / 16;
+    const uint64_t n_refs = O.n_refs, n_leaves = O.n_leaves;
+    const uint32_t max_depth = O.depth_bin;
     c->n_inner = n_out;
     c->n_refs = n_refs;
     c->n_leaves = n_leaves;
     c->max_depth = max_depth;
-    c->scene_bytes = nb + tb;
+    c->scene_bytes = nb + tb + wb;
     c->has_bvh = true;
     return PT_OK;
 }
@@ -490,7 +369,13 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     (void)need;  // any depth <= 64 works with every LDS window: deeper entries overflow
     int lstk = c->opt_lstk ? c->opt_lstk : PT_STACK_CAP;
     P.sc.stack_n = lstk;
-    P.sc.n_top = c->has_bvh ? (int)std::min<uint32_t>((uint32_t)c->opt_top, c->n_top_layout) : 0;
+    // the wide walk pushes up to three entries per level
+    int walk = c->opt_walk;
+    if (walk == 2 && (!c->has_bvh || 3 * c->wide_depth + 2 > (uint32_t)PT_STACK_CAP)) walk = 1;
+    P.sc.wide_root = (int)c->wide_root;
+    P.sc.top_base = walk == 2 ? (int)c->wide_root : 0;
+    P.sc.n_top = c->has_bvh ? (int)std::min<uint32_t>((uint32_t)c->opt_top, walk == 2 ? c->wide_top_layout : c->n_top_layout) : 0;
+    if (walk == 1) P.sc.n_top = 0;  // the binary unified-step walk reads every item from memory
     size_t lds = lds_bytes(P.sc.n_top, lstk, PT_BLOCK);
     while (lds > 160 * 1024 && P.sc.n_top > 0) {  // deep tree: give the LDS to the stack first
         P.sc.n_top /= 2;
@@ -523,7 +408,8 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     } while (0)
 #define PT_LAUNCH_ALG(COUNT, OCC, LSTK)                   \
     do {                                                  \
-        if (c->opt_walk == 1) PT_LAUNCH(COUNT, OCC, LSTK, 1); \
+        if (walk == 2) PT_LAUNCH(COUNT, OCC, LSTK, 2);    \
+        else if (walk == 1) PT_LAUNCH(COUNT, OCC, LSTK, 1); \
         else PT_LAUNCH(COUNT, OCC, LSTK, 0);              \
     } while (0)
 #define PT_LAUNCH_OCC(COUNT, LSTK)                            \
@@ -560,6 +446,8 @@ int pt_trace_rays(pt_ctx* c, const float* rays_dev, size_t n, int cull, float* t
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const float4* r4 = (const float4*)rays_dev;
     sc.stack_n = PT_STACK_CAP;
+    sc.top_base = 0;
+    sc.wide_root = (int)c->wide_root;
     sc.n_top = (int)std::min<uint32_t>((uint32_t)c->opt_top, c->n_top_layout);
     size_t lds = lds_bytes(sc.n_top, sc.stack_n, PT_BLOCK_RAYS);
     while (lds > 160 * 1024 && sc.n_top > 0) { sc.n_top /= 2; lds = lds_bytes(sc.n_top, sc.stack_n, PT_BLOCK_RAYS); }

@@ -445,7 +445,7 @@ void pth_default_build_params(pth_build_params* p) {
     p->n_bins = 32;
     p->sah_node_cost = 1.f;
     p->sah_tri_cost = 1.f;
-    p->split_alpha = -1.f;  // object splits only unless asked
+    p->split_alpha = 1e-5f;  // BuildParams::splitAlpha of the reference (SBVH)
     p->n_spatial_bins = 32;
 }
 

@@ -81,8 +81,13 @@ enum {
     PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the kernel's registers are budgeted for: 4/6/8 */
     PT_OPT_LDS_STACK = 7,     /* traversal-stack entries kept in LDS per lane: 16 (default) or
                                  0 = all 72; deeper entries overflow to private memory        */
-    PT_OPT_WALK = 8           /* closest-hit walk: 0 = while-while (Aila-Laine order, as the
-                                 reference), 1 = unified-step (default; same hits)            */
+    PT_OPT_WALK = 8,          /* closest-hit walk: 0 = while-while (Aila-Laine order, as the
+                                 reference), 1 = unified-step over the binary tree,
+                                 2 = wide (default): unified-step over a 4-way tree with
+                                 8-bit outward-rounded boxes; all three report the same hits  */
+    PT_OPT_LEAF_MAX = 9       /* leaves holding more triangle references than this are split
+                                 at the next pt_upload_bvh (0 = keep the producer's leaves;
+                                 default 2)                                                   */
 };
 
 /* CamInfo, GpuPathTracer/CpuStructs.hpp:19-28 (pitch/yaw/dirty/bias/enabled are host-only

@@ -43,6 +43,7 @@ def pt(request):
     t = g.PathTracer(0)
     t.set_option(g.OPT_KERNEL, k)
     t.set_option(g.OPT_WALK, walk)
+    t.set_option(g.OPT_LEAF_MAX, 0 if "whilewhile" in request.param else 2)
     t.set_option(g.OPT_OCCUPANCY, occ)
     t.set_option(g.OPT_LDS_STACK, lstk)
     t.set_option(g.OPT_TOP_NODES, top)
@@ -92,6 +93,10 @@ def gpu_trace(pt, rays, cull=True):
     return out
 
 
+def gpu_trace_frame_free(*a, **k):  # re-export hook for the sibling test modules
+    return gpu_trace(*a, **k)
+
+
 # ---------------------------------------------------------------- rows a5-a7: closest hit
 @pytest.mark.parametrize("name,n", [("cornell", 200_000), ("gto_sixteen", 200_000), ("dragon", 200_000), ("cube", 50_000)])
 @pytest.mark.parametrize("cull", [True, False])
@@ -129,9 +134,14 @@ def test_closest_hit_vs_bruteforce_and_reference_fixture(pt):
 
 def test_edge_case_rays(pt):
     """Zero direction components (ooeps substitution), rays starting inside boxes, rays that
-    miss everything, axis-parallel rays along box faces."""
+    miss everything, axis-parallel rays along box faces.  The last ray lies EXACTLY in a
+    bounding plane with a zero direction component: whether a slab test keeps such a ray is a
+    property of the individual boxes, so this case is checked on the producer's own tree
+    (PT_OPT_LEAF_MAX 0), the tree the oracle walks."""
     mesh, bvh = bvh_of("cornell")
+    pt.set_option(g.OPT_LEAF_MAX, 0)
     pt.upload_bvh(bvh)
+    pt.set_option(g.OPT_LEAF_MAX, 2)
     o = np.array([[0, 0, 0], [1, 2, 0], [0, 0, -40], [0, 0, -40], [0, 0, -40], [100, 100, 100], [0, 15.850145, -40]], np.float32)
     d = np.array([[0, 0, -1], [0, 0, -1], [0, -1, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], np.float32)
     rays = np.zeros((len(o), 8), np.float32)
@@ -291,11 +301,13 @@ def test_counters_and_algorithmic_bytes(pt):
     cam = golden_camera(W, H)
     p = g.default_params(W, H)
     pt.set_option(g.OPT_COUNTERS, 1)
+    pt.set_option(g.OPT_LEAF_MAX, 0)     # walk the producer's own leaves, like the oracle
     try:
         acc, _ = gpu_render(pt, bvh, sph, cam, p, 2)
         c = pt.counters()
     finally:
         pt.set_option(g.OPT_COUNTERS, 0)
+        pt.set_option(g.OPT_LEAF_MAX, 2)
     ref, _, c0 = orc.render(bvh, sph, cam, p, 2, want_rgba=False)
     assert np.array_equal(acc, ref)
     assert c["paths"] == c0["paths"] == W * H * 2

@@ -1,0 +1,95 @@
+"""GPU tests of the WIDE walk (PT_OPT_WALK = 2: 4-way tree, 8-bit outward-rounded child boxes).
+
+Parity class: leaves hold the exact triangle records, so every reported hit is the exact
+kernels' (t, id, normal); the quantised boxes can only let MORE candidates through, which
+matters only where the binary tree's own slab rounding culls a grazing true hit.  Bar:
+north_star's per-pixel L2 < 1e-3 against the oracle, plus a stated cap on differing
+pixels (they are counted and must stay at the 1e-5 level)."""
+import os
+
+import numpy as np
+import pytest
+
+import gpu_pathtracer_amd as g
+import orc
+from test_gpu_parity import gpu_render, golden_camera, l2, bvh_of
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module", params=[g.KERNEL_PERSISTENT, g.KERNEL_MEGA_BVH2], ids=["persistent-wide", "mega-wide"])
+def ptw(request):
+    t = g.PathTracer(0)
+    t.set_option(g.OPT_KERNEL, request.param)
+    t.set_option(g.OPT_WALK, 2)
+    yield t
+    t.close()
+
+
+@pytest.mark.parametrize("mat", [g.MAT_DIFF, g.MAT_METAL, g.MAT_SPEC, g.MAT_REFR])
+def test_wide_golden_images(ptw, mat):
+    z = np.load(os.path.join(GOLD, "oracle_images.npz"))
+    name = {g.MAT_DIFF: "diff", g.MAT_METAL: "metal", g.MAT_SPEC: "spec", g.MAT_REFR: "refr"}[mat]
+    _, bvh = bvh_of("cornell")
+    for spp in (1, 16):
+        p = g.default_params(64, 64, tri_mat=mat)
+        p.flags = g.FLAG_WRITE_RGBA
+        acc, rgba = gpu_render(ptw, bvh, g.reference_spheres(), golden_camera(64, 64), p, spp)
+        assert l2(acc, z[f"{name}_{spp}"]) < 1e-3
+        assert np.any(acc != z[f"{name}_{spp}"], axis=-1).sum() <= 1
+
+
+@pytest.mark.parametrize("scene,mat", [("cornell_dragon", g.MAT_DIFF), ("cornell_dragon", g.MAT_METAL),
+                                       ("gto_sixteen", g.MAT_SPEC), ("cornell_dragon_800k", g.MAT_DIFF)])
+def test_wide_full_frame_vs_oracle(ptw, scene, mat):
+    """1920x1080, depth 4, sphere room: every pixel against the oracle."""
+    W, H = 1920, 1080
+    _, bvh = bvh_of(scene)
+    sph = g.reference_spheres()
+    cam = g.default_camera(W, H)
+    p = g.default_params(W, H, tri_mat=mat)
+    p.frame = 5
+    acc, _ = gpu_render(ptw, bvh, sph, cam, p, 1)
+    ref, _, _ = orc.render(bvh, sph, cam, p, 1, want_rgba=False)
+    n_diff = int(np.any(acc != ref, axis=-1).sum())
+    err = l2(acc, ref)
+    print(f"wide {scene} mat {mat}: L2 {err:.3e}, differing pixels {n_diff} of {W * H}, scene {ptw.scene_info()}")
+    assert err < 1e-3
+    assert n_diff <= 40          # 2e-5 of the pixels
+
+
+def test_wide_open_scene_and_ragged(ptw):
+    """No spheres (paths die on a miss, lanes refill), ragged image sizes, several spp."""
+    _, bvh = bvh_of("dragon")
+    for W, H in ((129, 71), (640, 360)):
+        cam = golden_camera(W, H)
+        p = g.default_params(W, H)
+        acc, _ = gpu_render(ptw, bvh, None, cam, p, 3)
+        ref, _, _ = orc.render(bvh, None, cam, p, 3, want_rgba=False)
+        assert l2(acc, ref) < 1e-3
+        assert np.any(acc != ref, axis=-1).sum() <= 2
+
+
+def test_wide_equals_exact_kernel_on_hits(ptw):
+    """Same frame through the exact unified walk and the wide walk on one device; the
+    instrumented counters show the wide walk fetches far fewer node items."""
+    W, H = 960, 540
+    _, bvh = bvh_of("cornell_dragon")
+    sph = g.reference_spheres()
+    cam = golden_camera(W, H)
+    p = g.default_params(W, H)
+    ptw.set_option(g.OPT_COUNTERS, 1)
+    a_w, _ = gpu_render(ptw, bvh, sph, cam, p, 2)
+    c_w = ptw.counters()
+    ptw.set_option(g.OPT_WALK, 1)
+    try:
+        a_e, _ = gpu_render(ptw, bvh, sph, cam, p, 2)
+        c_e = ptw.counters()
+    finally:
+        ptw.set_option(g.OPT_WALK, 2)
+        ptw.set_option(g.OPT_COUNTERS, 0)
+    print("wide counters", c_w, "exact counters", c_e)
+    assert np.any(a_w != a_e, axis=-1).sum() <= 10
+    assert c_w["rays"] == c_e["rays"] and c_w["hits"] >= c_e["hits"] - 10
+    assert c_w["inner"] < 0.75 * c_e["inner"]

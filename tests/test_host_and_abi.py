@@ -75,8 +75,11 @@ def test_cornell_matches_reference_counts_and_fixture():
 
 
 def test_child_boxes_enclose_their_triangles():
+    """Object splits only: a leaf box holds its triangles whole.  (With spatial splits a leaf box
+    holds only the clipped part of a duplicated reference; that tree is checked against brute
+    force in test_oracle.py.)"""
     mesh = g.scene_mesh("bunny_low")
-    bvh = g.Bvh(mesh)
+    bvh = g.Bvh(mesh, split_alpha=-1.0)
     nodes, tb = bvh.nodes.reshape(-1, 16), bits(bvh.tris)
     for nd in nodes:
         for ci in range(2):
@@ -117,6 +120,16 @@ def test_obj_reader(tmp_path):
     bad.write_text("v 0 0 0\nf 1 2 3\n")
     with pytest.raises(RuntimeError):
         g.Mesh.load(str(bad))
+
+
+def test_sbvh_statistics_track_the_reference_builder():
+    """Default build params = the reference's (Platform costs 1:1, splitAlpha 1e-5).  The
+    reference's own builder+flatten gives 18 124 node vec4 / 52 409 tri vec4 / 4 532 leaves on
+    gto_sixteen.obj (SURVEY.md §8c probe); ours must land within a few percent."""
+    b = g.Bvh(g.scene_mesh("gto_sixteen"))
+    assert abs(len(b.nodes) - 18124) / 18124 < 0.05
+    assert abs(len(b.tris) - 52409) / 52409 < 0.08
+    assert abs(b.stats["n_leaves"] - 4532) / 4532 < 0.05
 
 
 def test_scene_synthesis_is_deterministic():

@@ -63,8 +63,8 @@ def test_spatial_split_tree_gives_same_hits():
     mesh = g.scene_mesh("gto_sixteen")
     lo, hi = mesh.bounds()
     rays = orc.random_rays(4000, lo, hi, seed=5)
-    a = g.Bvh(mesh)
-    b = g.Bvh(mesh, split_alpha=1e-5)
+    a = g.Bvh(mesh, split_alpha=-1.0)     # object splits only
+    b = g.Bvh(mesh)                       # default: the reference's splitAlpha = 1e-5
     assert b.stats["n_tri_refs"] >= a.stats["n_tri_refs"]
     ta, ia, _, _ = orc.trace_bvh(a, rays)
     tb, ib, _, _ = orc.trace_bvh(b, rays)

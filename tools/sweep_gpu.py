@@ -15,14 +15,23 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--mat", type=int, default=0)
 ap.add_argument("--no-spheres", action="store_true")
+ap.add_argument("--bvh", default="", help="builder overrides, e.g. split_alpha=1e-5,sah_tri_cost=2")
+ap.add_argument("--leaf-max", type=int, default=2)
 ap.add_argument("--variants", default="mega::64:8:16:0,mega::0:8:16:1,mega::0:6:16:1,mega::0:4:16:1,persist:16:0:8:16:1,persist:16:0:6:16:1,persist:16:0:4:16:1,persist:8:0:8:16:1,persist:32:0:8:16:1,persist:16:64:8:16:0",
                 help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack[:walk]]]]]")
 a = ap.parse_args()
 
 W, H = a.width, a.height
-bvh = g.Bvh(g.scene_mesh(a.scene))
+kw = {}
+for item in filter(None, a.bvh.split(",")):
+    k, v = item.split("=")
+    kw[k] = float(v) if k in ("split_alpha", "sah_tri_cost", "sah_node_cost") else int(v)
+bvh = g.Bvh(g.scene_mesh(a.scene), **kw)
+print("bvh", kw, bvh.stats)
 pt = g.PathTracer(0)
+pt.set_option(g.OPT_LEAF_MAX, a.leaf_max)
 pt.upload_bvh(bvh)
+print("leaf_max", a.leaf_max, pt.scene_info())
 pt.upload_spheres(None if a.no_spheres else g.reference_spheres())
 cam = g.default_camera(W, H)
 acc, rgba = pt.alloc_frame(W, H)
