@@ -359,17 +359,25 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
             const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
             const int nch = (int)(meta >> 24);
+            // entry/exit planes per axis follow the sign of the ray direction, so pick the packed
+            // byte quadruples ONCE per node (6 v_cndmask) instead of min/max per child (24):
+            // identical values to min(lo,hi)/max(lo,hi) of the reference's slab test
             const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
             const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
+            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+            const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx;
+            const uint32_t ny = py ? qly : qhy, fy = py ? qhy : qly;
+            const uint32_t nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
             const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
             uint32_t key[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float lx = fmaf((float)((qlx >> (8 * k)) & 0xffu), sx, bx), hx = fmaf((float)((qhx >> (8 * k)) & 0xffu), sx, bx);
-                const float ly = fmaf((float)((qly >> (8 * k)) & 0xffu), sy, by), hy = fmaf((float)((qhy >> (8 * k)) & 0xffu), sy, by);
-                const float lz = fmaf((float)((qlz >> (8 * k)) & 0xffu), sz, bz), hz = fmaf((float)((qhz >> (8 * k)) & 0xffu), sz, bz);
-                const float tmin = fmaxf(fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fminf(lz, hz)), 0.0f);
-                const float tmax = fminf(fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fmaxf(lz, hz)), h.t);
+                // (entry, exit) of one axis in one v_pk_fma_f32
+                const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
+                const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
+                const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
+                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
                 const bool hit = (k < nch) && (tmin <= tmax);
                 key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
             }

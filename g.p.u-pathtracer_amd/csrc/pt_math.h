@@ -16,6 +16,11 @@ struct v3 {
     float x, y, z;
 };
 
+// two binary32 lanes for v_pk_fma_f32 (each half is an IEEE fused multiply-add)
+typedef float pt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pt_f2 pt_mk2(float a, float b) { pt_f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ pt_f2 pt_fma2(pt_f2 a, pt_f2 b, pt_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 __device__ __forceinline__ v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 __device__ __forceinline__ v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
