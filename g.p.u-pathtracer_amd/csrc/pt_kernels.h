@@ -94,15 +94,32 @@ struct TravState {
 // mix of depths is conflict-free); deeper entries — rare: the walk pushes one entry per level
 // that has both children hit — overflow into a private (scratch) array.  A small LSTK is what
 // lets 6-8 waves per SIMD fit in the CU's 160 KiB of LDS (64 B/lane at LSTK = 16).
+// lane id recomputed where it is used (2 VALU): kept in a register across the walk it is the
+// first thing hipcc spills at 64-80 VGPRs, and a scratch reload in front of every push/pop
+// puts a vector-memory round trip on the loop's critical path
+__device__ __forceinline__ int pt_lane_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <int LSTK>
+struct TravOverflow {
+    int e[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
+};
+
 template <int LSTK, int BLOCK>
 struct TravStack {
-    int base;  // int index of this lane's entry 0 inside s_dyn (the __shared__ symbol is named in
-               // the accessors so that the loads stay ds_read/ds_write: a stored pointer makes
-               // hipcc merge the LDS and overflow paths into flat_load/flat_store)
-    int ovf[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
+    int base;  // WAVE-UNIFORM int index of lane 0's entry 0 inside s_dyn (the __shared__ symbol is
+               // named in the accessors so that the accesses stay ds_read/ds_write: a stored
+               // pointer makes hipcc merge the LDS and overflow paths into flat_load/flat_store)
+    // the overflow array is a SEPARATE private object: as a member it drags the whole struct,
+    // `base` included, into scratch memory (a scratch reload in front of every push)
+    int (&ovf)[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
+    __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK>& o) : base(b), ovf(o.e) {}
     __device__ __forceinline__ void put(int sp, int v) {
         if (LSTK >= PT_STACK_CAP || sp < LSTK) {
-            ((int*)s_dyn)[base + sp * BLOCK] = v;
+            ((int*)s_dyn)[base + sp * BLOCK + pt_lane_fresh()] = v;
         } else {
             asm volatile("" : "+v"(v));
             ovf[sp - LSTK] = v;
@@ -111,7 +128,7 @@ struct TravStack {
     __device__ __forceinline__ int get(int sp) const {
         int v;
         if (LSTK >= PT_STACK_CAP || sp < LSTK) {
-            v = ((const int*)s_dyn)[base + sp * BLOCK];
+            v = ((const int*)s_dyn)[base + sp * BLOCK + pt_lane_fresh()];
         } else {
             v = ovf[sp - LSTK];
             asm volatile("" : "+v"(v));
@@ -668,8 +685,8 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams
     const int px = tx * PT_TILE + (lane & 7), py = ty * PT_TILE + (lane >> 3);
     if (px >= P.W || py >= P.H) return;  // tracer.cu:358
     const uint64_t pix = (uint64_t)py * (uint64_t)P.W + (uint64_t)px;
-    TravStack<LSTK, PT_BLOCK> stk;
-    stk.base = 16 * P.sc.n_top + tid;
+    TravOverflow<LSTK> stk_ovf;
+    TravStack<LSTK, PT_BLOCK> stk(__builtin_amdgcn_readfirstlane(16 * P.sc.n_top + (tid & ~63)), stk_ovf);
 
     TravCount tc;
     tc.inner = tc.tris = tc.leaves = 0;
@@ -709,8 +726,8 @@ __global__ void __launch_bounds__(PT_BLOCK_RAYS) k_trace_rays_bvh2(const KScene 
     const float4 ro = rays[2 * i], rd = rays[2 * i + 1];
     TravCount tc;
     tc.inner = tc.tris = tc.leaves = 0;
-    TravStack<PT_STACK_CAP, PT_BLOCK_RAYS> stk;
-    stk.base = 16 * sc.n_top + (int)threadIdx.x;
+    TravOverflow<PT_STACK_CAP> stk_ovf;
+    TravStack<PT_STACK_CAP, PT_BLOCK_RAYS> stk(__builtin_amdgcn_readfirstlane(16 * sc.n_top + ((int)threadIdx.x & ~63)), stk_ovf);
     const Hit h = trav_bvh2<false, true>(sc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), cull != 0, stk, tc, s_top);
     t_out[i] = h.t;
     tri_out[i] = h.tri;
@@ -739,8 +756,8 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
     lds_load_top<PT_BLOCK>(P.sc, s_top);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    TravStack<LSTK, PT_BLOCK> stk;
-    stk.base = 16 * P.sc.n_top + tid;
+    TravOverflow<LSTK> stk_ovf;
+    TravStack<LSTK, PT_BLOCK> stk(__builtin_amdgcn_readfirstlane(16 * P.sc.n_top + (tid & ~63)), stk_ovf);
     const bool cull = P.cull != 0;
     const uint32_t total = (uint32_t)P.n_tiles * 64u;
 
