@@ -40,7 +40,7 @@ for v in a.variants.split(","):
     parts = v.split(":") + ["", "", "", "", ""]
     variants.append((v, {"mega": g.KERNEL_MEGA_BVH2, "persist": g.KERNEL_PERSISTENT, "wide": g.KERNEL_MEGA_WIDE}[parts[0]],
                      int(parts[1]) if parts[1] else 16, int(parts[2]) if parts[2] else 64,
-                     int(parts[3]) if parts[3] else 8, int(parts[4]) if parts[4] else 16, int(parts[5]) if parts[5] else 1))
+                     int(parts[3]) if parts[3] else 5, int(parts[4]) if parts[4] else 16, int(parts[5]) if parts[5] else 2))
 res = {v[0]: [] for v in variants}
 for r in range(a.rounds + 1):
     for name, k, batch, top, occ, lstk, walk in variants:
