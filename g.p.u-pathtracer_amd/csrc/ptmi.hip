@@ -165,7 +165,7 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             c->opt_top = value;
             return PT_OK;
         case PT_OPT_OCCUPANCY:
-            if (value != 4 && value != 6 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: occupancy must be 4, 6 or 8 waves per SIMD");
+            if (value != 4 && value != 5 && value != 6 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: occupancy must be 4, 5, 6 or 8 waves per SIMD");
             c->opt_occ = value;
             return PT_OK;
         case PT_OPT_LEAF_MAX:
@@ -416,6 +416,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     do {                                                      \
         if (c->opt_occ == 8) PT_LAUNCH_ALG(COUNT, 8, LSTK);   \
         else if (c->opt_occ == 6) PT_LAUNCH_ALG(COUNT, 6, LSTK); \
+        else if (c->opt_occ == 5) PT_LAUNCH_ALG(COUNT, 5, LSTK); \
         else PT_LAUNCH_ALG(COUNT, 4, LSTK);                   \
     } while (0)
     if (c->opt_counters) {
