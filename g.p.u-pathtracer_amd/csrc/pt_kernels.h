@@ -632,7 +632,7 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
             if (ALG == 2) {
                 TravState ts;
                 trav_begin(ts, ps.o, ps.d, stk, P.sc.wide_root);
-                trav_run_wide<COUNT, false, true, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
+                trav_run_wide<COUNT, false, false, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
                 h = ts.h;
             } else if (ALG == 1) {
                 TravState ts;
@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         {
             const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
             if (phase == PH_TRAV) {
-                const bool fin = (ALG == 2)   ? trav_run_wide<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                const bool fin = (ALG == 2)   ? trav_run_wide<COUNT, true, false>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                  : (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                               : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
                 if (fin) phase = PH_SHADE;
