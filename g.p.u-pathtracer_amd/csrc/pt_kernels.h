@@ -343,7 +343,20 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
     int cur = s.node, sp = s.sp;
     Hit h = s.h;
     const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
-    while (cur != PT_SENTINEL) {
+    for (;;) {
+        // phase vote: the wave runs ONE kind of step per iteration, the kind most live lanes are
+        // waiting for; the others sit this iteration out.  Node and record lanes no longer both
+        // pay for each other's code every iteration (the limiter is VALU issue).
+        // The loop is wave-uniform: every lane that entered stays until the common exit.
+        const bool live = cur != PT_SENTINEL;
+        const bool is_node = live && cur >= 0;
+        const int n_live = __popcll(__ballot(live));
+        if (n_live == 0) break;
+        if (DYN && 64 - n_live - n_dead >= batch) break;  // enough lanes wait for service
+        const int n_node = __popcll(__ballot(is_node));
+        // a record step costs about half a node step: run whichever advances more lanes per instruction
+        const bool node_phase = n_node >= 2 * (n_live - n_node);
+        if (!live || is_node != node_phase) continue;
         const int a = cur >= 0 ? cur : ~cur;
         float4 q0, q1, q2;
         int l2 = 0, l3 = 0;
@@ -432,10 +445,6 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             } else {
                 cur -= 4;  // ~(a + 4)
             }
-        }
-        if (DYN) {  // enough lanes are waiting for service: hand the wave back
-            const int active = __popcll(__ballot(cur != PT_SENTINEL));
-            if (64 - active - n_dead >= batch) break;
         }
     }
     s.node = cur; s.sp = sp; s.h = h;

@@ -48,7 +48,7 @@ struct pt_ctx {
     unsigned long long* d_counters = nullptr;
     unsigned int* d_queue = nullptr;   // persistent kernel's work counter
     int n_cu = 0;
-    int opt_batch = 32;
+    int opt_batch = 40;
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
     int opt_occ = 6;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
