@@ -31,8 +31,11 @@ struct KScene {
     int wide_root; // float4 index of the 4-wide quantised tree's root (pt_wide.h), 0 if absent
 };
 
+#define PT_KSPHERES 8   // spheres carried in the kernel-argument block (scalar loads); more -> global array
+
 struct KParams {
     KScene sc;
+    pt_sphere_d ksph[PT_KSPHERES];
     float* __restrict__ accum;
     uint32_t* __restrict__ rgba;
     unsigned long long* counters;      // 6 x u64 when instrumented
@@ -506,10 +509,25 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     float scene_t = h.t;
     if (h.tri != -1) geom = 0;
     // intersectAllSpeheres, cudaUtils.h:221-236 (uniform loop, scalar loads)
-    for (int i = 0; i < P.sc.n_spheres; i++) {
-        const pt_sphere_d& s = P.sc.spheres[i];
-        const float ts = pt_sphere_intersect(s.px, s.py, s.pz, s.rad, o, d);
-        if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
+    // The reference scene has 8 spheres (BasicScene.cpp:181-202): they ride in the kernel-argument
+    // block and the loop is unrolled, so the data arrives by scalar loads issued up front.  Inside
+    // the divergent service phase hipcc otherwise keeps the loop counter in a VGPR and fetches each
+    // sphere with dependent vector loads (a quarter of the kernel's vector-memory instructions).
+    if (P.sc.n_spheres <= PT_KSPHERES) {
+#pragma unroll
+        for (int i = 0; i < PT_KSPHERES; i++) {
+            if (i < P.sc.n_spheres) {
+                const pt_sphere_d& s = P.ksph[i];
+                const float ts = pt_sphere_intersect(s.px, s.py, s.pz, s.rad, o, d);
+                if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
+            }
+        }
+    } else {
+        for (int i = 0; i < P.sc.n_spheres; i++) {
+            const pt_sphere_d& s = P.sc.spheres[i];
+            const float ts = pt_sphere_intersect(s.px, s.py, s.pz, s.rad, o, d);
+            if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
+        }
     }
     v3 hitpos = vmadd(d, scene_t, o);
     v3 n, nl, objcol, emit;

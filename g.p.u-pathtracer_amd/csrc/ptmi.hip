@@ -33,6 +33,7 @@ struct pt_ctx {
     float4* d_tris = nullptr;
     pt_sphere_d* d_spheres = nullptr;
     int n_spheres = 0;
+    pt_sphere_d h_spheres[PT_KSPHERES];   // host copy of the first spheres for the kernel-argument block
     uint64_t n_inner = 0, n_refs = 0, n_leaves = 0, scene_bytes = 0;
     uint32_t max_depth = 0;
     uint32_t n_top_layout = 0;   // nodes [0, n_top_layout) are in breadth-first order
@@ -50,7 +51,7 @@ struct pt_ctx {
     int n_cu = 0;
     int opt_batch = 40;
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
-    int opt_occ = 6;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
+    int opt_occ = 5;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
     int opt_walk = 2;            // 0 while-while, 1 unified-step, 2 wide (PT_OPT_WALK)
     int opt_leaf_max = 2;        // leaves with more references are split at upload (PT_OPT_LEAF_MAX)
@@ -297,6 +298,7 @@ int pt_upload_spheres(pt_ctx* c, const pt_sphere* spheres, size_t n) {
         HIP_TRY(c, hipMalloc((void**)&c->d_spheres, n * sizeof(pt_sphere)));
         HIP_TRY(c, hipMemcpy(c->d_spheres, spheres, n * sizeof(pt_sphere), hipMemcpyHostToDevice));
         c->n_spheres = (int)n;
+        std::memcpy(c->h_spheres, spheres, std::min<size_t>(n, PT_KSPHERES) * sizeof(pt_sphere));
     }
     return PT_OK;
 }
@@ -334,6 +336,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     P.sc.tris = c->d_tris;
     P.sc.spheres = c->d_spheres;
     P.sc.n_spheres = c->n_spheres;
+    std::memcpy(P.ksph, c->h_spheres, sizeof P.ksph);
     P.sc.has_bvh = c->has_bvh ? 1 : 0;
     P.accum = accum_dev;
     P.rgba = rgba_dev;
