@@ -93,3 +93,36 @@ def test_wide_equals_exact_kernel_on_hits(ptw):
     assert np.any(a_w != a_e, axis=-1).sum() <= 10
     assert c_w["rays"] == c_e["rays"] and c_w["hits"] >= c_e["hits"] - 10
     assert c_w["inner"] < 0.75 * c_e["inner"]
+
+
+def test_config5_open_scene_4096_tile_split(ptw):
+    """BASELINE.json configs[4] flavour: dragon.obj, 4096x4096, no sphere room (paths die on the
+    first miss, so lanes are refilled constantly), rendered as an 8-way stripe split on one GPU
+    and compared, every pixel, with the oracle and with the unsplit render."""
+    W = H = 4096
+    _, bvh = bvh_of("dragon")
+    cam = g.default_camera(W, H)
+    cam.dist = 18.0   # the reference's dist = H/60 = 68 would start every ray BEHIND the dragon
+    ptw.upload_bvh(bvh)
+    ptw.upload_spheres(None)
+    acc, rgba = ptw.alloc_frame(W, H)
+    for part in range(8):
+        p = g.default_params(W, H)
+        p.part_index, p.part_count, p.part_rows = part, 8, 8
+        ptw.launch_kernel(acc.ptr, rgba.ptr, cam, p, 1)
+    ptw.sync()
+    split = acc.download(np.float32, (H, W, 3))
+    acc.zero()
+    p = g.default_params(W, H)
+    ptw.launch_kernel(acc.ptr, rgba.ptr, cam, p, 1)
+    ptw.sync()
+    whole = acc.download(np.float32, (H, W, 3))
+    acc.free()
+    rgba.free()
+    assert np.array_equal(split, whole)
+    ref, _, cnt = orc.render(bvh, None, cam, p, 1, want_rgba=False)
+    assert W * H * 1.02 < cnt["rays"] < W * H * p.depth   # open scene: paths end on their first miss
+    n_diff = int(np.any(whole != ref, axis=-1).sum())
+    print(f"config5 4096^2 open scene: segments {cnt['rays']}, differing pixels {n_diff}")
+    assert l2(whole, ref) < 1e-3
+    assert n_diff <= 64
