@@ -340,7 +340,9 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
 // nearest and pushes the rest far-to-near.  Record items are the exact Moller-Trumbore test of
 // the other walks, so a reported hit is bit-identical to theirs; only the set of candidates the
 // (outward-rounded) boxes let through differs.  3 pieces for a record, 4 for a node.
-template <bool COUNT, bool DYN, bool TOP, class STK>
+// WOOP: records hold Woop's affine rows (PT_OPT_TRI_TEST 1) instead of v0/e1/e2 — see
+// pt_woop_intersect in pt_math.h; tolerance-class parity (the triangle arithmetic differs).
+template <bool COUNT, bool DYN, bool TOP, bool WOOP, class STK>
 __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
                                               TravCount& tc, int n_dead, int batch) {
     int cur = s.node, sp = s.sp;
@@ -362,6 +364,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         if (!live || is_node != node_phase) continue;
         const int a = cur >= 0 ? cur : ~cur;
         float4 q0, q1, q2;
+        float4 qw = make_float4(0.f, 0.f, 0.f, 0.f);  // WOOP: a record's 4th piece (normal | id<<1|last)
         int l2 = 0, l3 = 0;
         const int ti = a - sc.top_base;
         if (TOP && cur >= 0 && (unsigned)ti < (unsigned)(sc.n_top * 4)) {
@@ -377,10 +380,11 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             q0 = sc.nodes[a + 0];
             q1 = sc.nodes[a + 1];
             q2 = sc.nodes[a + 2];
-            if (cur >= 0) {
+            if (WOOP || cur >= 0) {
                 const float4 q3 = sc.nodes[a + 3];
                 l2 = __float_as_int(q3.x);
                 l3 = __float_as_int(q3.y);
+                qw = q3;
             }
             asm volatile("" : "+v"(l2), "+v"(l3));
         }
@@ -432,16 +436,30 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             if (COUNT && cur < 0) tc.leaves++;
         } else {
             if (COUNT) tc.tris++;
-            const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
-            const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
-            const int id = __float_as_int(q0.w);
+            float t;
+            int id;
+            bool last;
+            if (WOOP) {
+                t = pt_woop_intersect(q0, q1, q2, V3(qw.x, qw.y, qw.z), o, d, cull);
+                id = __float_as_int(qw.w) >> 1;
+                last = (__float_as_int(qw.w) & 1) != 0;
+            } else {
+                const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+                t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+                id = __float_as_int(q0.w);
+                last = __float_as_int(q1.w) != 0;
+            }
             if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                 h.t = t;
                 h.tri = id;
-                const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
-                h.n = V3(q3.x, q3.y, q3.z);
+                if (WOOP) {
+                    h.n = V3(qw.x, qw.y, qw.z);
+                } else {
+                    const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
+                    h.n = V3(q3.x, q3.y, q3.z);
+                }
             }
-            if (__float_as_int(q1.w) != 0) {  // last record of the leaf
+            if (last) {  // last record of the leaf
                 cur = stk.get(sp);
                 sp--;
                 if (COUNT && cur < 0 && cur != PT_SENTINEL) tc.leaves++;
@@ -656,10 +674,10 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
         Hit h;
         h.t = PT_F32_MAX; h.tri = -1; h.n = V3(0.f, 0.f, 0.f);
         if (P.sc.has_bvh) {
-            if (ALG == 2) {
+            if (ALG >= 2) {
                 TravState ts;
                 trav_begin(ts, ps.o, ps.d, stk, P.sc.wide_root);
-                trav_run_wide<COUNT, false, false, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
+                trav_run_wide<COUNT, false, false, ALG == 3, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
                 h = ts.h;
             } else if (ALG == 1) {
                 TravState ts;
@@ -699,7 +717,8 @@ __device__ __forceinline__ bool pt_tile_coords(const KParams& P, int tile, int& 
 // trace<<<>>>, tracer.cu:343-400: one lane per pixel, one wave per 8x8 tile, `spp`
 // consecutive samples folded in registers.
 // OCC = waves per SIMD the register allocator must leave room for (4 / 6 / 8)
-// ALG = 0 while-while walk (Aila-Laine), 1 unified-step walk, 2 wide (4-way quantised) walk
+// ALG = 0 while-while walk (Aila-Laine), 1 unified-step walk, 2 wide (4-way quantised) walk,
+//       3 wide walk over Woop records
 template <bool COUNT, int OCC, int LSTK, int ALG>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams P) {
     float4* s_top = s_dyn;
@@ -858,7 +877,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                 phase = PH_SHADE;
                 ts.h.t = PT_F32_MAX; ts.h.tri = -1;
             } else if (P.sc.has_bvh) {
-                trav_begin(ts, ps.o, ps.d, stk, ALG == 2 ? P.sc.wide_root : 0);
+                trav_begin(ts, ps.o, ps.d, stk, ALG >= 2 ? P.sc.wide_root : 0);
                 phase = PH_TRAV;
             } else {
                 ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.n = V3(0.f, 0.f, 0.f);
@@ -870,7 +889,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         {
             const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
             if (phase == PH_TRAV) {
-                const bool fin = (ALG == 2)   ? trav_run_wide<COUNT, true, false>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                const bool fin = (ALG >= 2)   ? trav_run_wide<COUNT, true, false, ALG == 3>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                  : (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                               : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
                 if (fin) phase = PH_SHADE;
@@ -889,7 +908,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             }
             if (!done) {
                 if (P.sc.has_bvh) {
-                    trav_begin(ts, ps.o, ps.d, stk, ALG == 2 ? P.sc.wide_root : 0);
+                    trav_begin(ts, ps.o, ps.d, stk, ALG >= 2 ? P.sc.wide_root : 0);
                     phase = PH_TRAV;
                 }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
             } else {

@@ -142,6 +142,25 @@ __device__ __forceinline__ float pt_mt_intersect(v3 v0, v3 e1, v3 e2, v3 o, v3 d
     return miss ? PT_F32_MAX : t;
 }
 
+// Woop's ray/triangle test on the affine rows W = M^-1, M = columns (v0-v2, v1-v2, n, v2),
+// n = (v0-v2)x(v1-v2), as the reference MEANT to build them (CudaBVH.cpp:274-305; its column 3 is
+// wrong, SURVEY.md F4, and its kernel never reads them, F3):  rz = (W row 2, w negated),
+// rx = W row 0, ry = W row 1.  Accept/cull rules are the Moller-Trumbore ones of
+// cudaUtils.h:151-166 with det taken as -dot(d, N), N = cross(v0-v1, v0-v2) (4th record piece).
+__device__ __forceinline__ float pt_woop_intersect(float4 rz, float4 rx, float4 ry, v3 N, v3 o, v3 d, bool cull) {
+    const float EPS = 0.00001f;
+    const float Oz = rz.w - vdot(o, V3(rz.x, rz.y, rz.z));
+    const float Dz = vdot(d, V3(rz.x, rz.y, rz.z));
+    const float t = Oz * (1.0f / Dz);
+    const float u = fmaf(t, vdot(d, V3(rx.x, rx.y, rx.z)), rx.w + vdot(o, V3(rx.x, rx.y, rx.z)));
+    const float v = fmaf(t, vdot(d, V3(ry.x, ry.y, ry.z)), ry.w + vdot(o, V3(ry.x, ry.y, ry.z)));
+    const float det = -vdot(d, N);
+    bool miss = (det < -EPS) ? cull : (det < EPS);
+    miss = miss || (u < 0.0f) || (v < 0.0f) || ((u + v) > 1.0f);
+    miss = miss || !(t > 0.0f && t < PT_F32_MAX);
+    return miss ? PT_F32_MAX : t;
+}
+
 // Sphere, GpuPathTracer/CommomStructs.hpp:18-39 (44 bytes)
 struct pt_sphere_d {
     float px, py, pz, rad;

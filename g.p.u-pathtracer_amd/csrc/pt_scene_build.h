@@ -217,7 +217,7 @@ inline void bfs_then_dfs(size_t n, size_t max_top, KidsFn kids, std::vector<size
 
 struct WNode { Box3 cb[4]; int64_t child[4]; int n; };  // child >= 0: wide index, < 0: ~leaf index
 
-inline void emit(const Tree& T, size_t max_top, Output& out) {
+inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false) {
     // reachable binary nodes, depth-first (also the record emission order)
     std::vector<size_t> reach;
     std::vector<int32_t> leaf_first(T.leaves.size(), -1);  // float4 index of a leaf's first record (relative)
@@ -242,14 +242,42 @@ inline void emit(const Tree& T, size_t max_top, Output& out) {
                     // cross(v0-v1, v0-v2) with the kernels' vcross arithmetic (cudaUtils.h:432)
                     const float ax = v0[0] - v1[0], ay = v0[1] - v1[1], az = v0[2] - v1[2];
                     const float bx = v0[0] - v2[0], by = v0[1] - v2[1], bz = v0[2] - v2[2];
-                    const float rec[16] = {v0[0], v0[1], v0[2], i2f(r.id),
-                                           v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], i2f(k + 1 == lf.count ? 1 : 0),
-                                           v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f,
-                                           std::fmaf(ay, bz, -(az * by)), std::fmaf(az, bx, -(ax * bz)), std::fmaf(ax, by, -(ay * bx)), 0.f};
-                    out.rec.insert(out.rec.end(), rec, rec + 16);
+                    const float N[3] = {std::fmaf(ay, bz, -(az * by)), std::fmaf(az, bx, -(ax * bz)), std::fmaf(ax, by, -(ay * bx))};
+                    const int last = k + 1 == lf.count ? 1 : 0;
+                    if (woop) {
+                        // W = M^-1, M = columns (a, b, n, v2), a = v0-v2, b = v1-v2, n = a x b (n is
+                        // orthogonal to a and b, so the rows are (b x n, n x a, n) / |n|^2); binary64
+                        const double A[3] = {(double)v0[0] - v2[0], (double)v0[1] - v2[1], (double)v0[2] - v2[2]};
+                        const double B[3] = {(double)v1[0] - v2[0], (double)v1[1] - v2[1], (double)v1[2] - v2[2]};
+                        const double n[3] = {A[1] * B[2] - A[2] * B[1], A[2] * B[0] - A[0] * B[2], A[0] * B[1] - A[1] * B[0]};
+                        const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                        double r0[3] = {0, 0, 0}, r1[3] = {0, 0, 0}, r2[3] = {0, 0, 0};
+                        if (nn > 0.0) {
+                            const double bn[3] = {B[1] * n[2] - B[2] * n[1], B[2] * n[0] - B[0] * n[2], B[0] * n[1] - B[1] * n[0]};
+                            const double na[3] = {n[1] * A[2] - n[2] * A[1], n[2] * A[0] - n[0] * A[2], n[0] * A[1] - n[1] * A[0]};
+                            for (int x = 0; x < 3; x++) { r0[x] = bn[x] / nn; r1[x] = na[x] / nn; r2[x] = n[x] / nn; }
+                        }
+                        const double t0 = -(r0[0] * v2[0] + r0[1] * v2[1] + r0[2] * v2[2]);
+                        const double t1 = -(r1[0] * v2[0] + r1[1] * v2[1] + r1[2] * v2[2]);
+                        const double t2 = -(r2[0] * v2[0] + r2[1] * v2[1] + r2[2] * v2[2]);
+                        const float rec[16] = {(float)r2[0], (float)r2[1], (float)r2[2], (float)(-t2),
+                                               (float)r0[0], (float)r0[1], (float)r0[2], (float)t0,
+                                               (float)r1[0], (float)r1[1], (float)r1[2], (float)t1,
+                                               N[0], N[1], N[2], i2f((int32_t)(((uint32_t)r.id << 1) | (uint32_t)last))};
+                        out.rec.insert(out.rec.end(), rec, rec + 16);
+                    } else {
+                        const float rec[16] = {v0[0], v0[1], v0[2], i2f(r.id),
+                                               v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], i2f(last),
+                                               v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f,
+                                               N[0], N[1], N[2], 0.f};
+                        out.rec.insert(out.rec.end(), rec, rec + 16);
+                    }
                 }
                 if (lf.count == 0) {  // empty leaf: one degenerate record that can never be hit
-                    const float rec[16] = {0, 0, 0, i2f(-1), 0, 0, 0, i2f(1), 0, 0, 0, 0, 0, 0, 0, 0};
+                    // MT: id -1, last = 1, zero edges (det = 0);  Woop: zero rows (t = 0/0), id<<1|last
+                    const float rec_mt[16] = {0, 0, 0, i2f(-1), 0, 0, 0, i2f(1), 0, 0, 0, 0, 0, 0, 0, 0};
+                    const float rec_w[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, i2f(-1)};
+                    const float* rec = woop ? rec_w : rec_mt;
                     out.rec.insert(out.rec.end(), rec, rec + 16);
                     cnt = 1;
                 }

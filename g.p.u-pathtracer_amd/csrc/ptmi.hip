@@ -55,6 +55,8 @@ struct pt_ctx {
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
     int opt_walk = 2;            // 0 while-while, 1 unified-step, 2 wide (PT_OPT_WALK)
     int opt_leaf_max = 2;        // leaves with more references are split at upload (PT_OPT_LEAF_MAX)
+    int opt_tri_test = 0;        // 0 Moller-Trumbore records, 1 Woop records (next upload; PT_OPT_TRI_TEST)
+    bool records_woop = false;   // what the uploaded records are
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
 };
@@ -169,6 +171,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value != 4 && value != 5 && value != 6 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: occupancy must be 4, 5, 6 or 8 waves per SIMD");
             c->opt_occ = value;
             return PT_OK;
+        case PT_OPT_TRI_TEST:
+            if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: tri test must be 0 (Moller-Trumbore) or 1 (Woop)");
+            c->opt_tri_test = value;   // takes effect at the next pt_upload_bvh
+            return PT_OK;
         case PT_OPT_LEAF_MAX:
             if (value < 0 || value > 1024) return fail(c, PT_ERR_INVALID, "pt_set_option: leaf_max must be 0 (keep) .. 1024");
             c->opt_leaf_max = value;   // takes effect at the next pt_upload_bvh
@@ -253,7 +259,7 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
         return fail(c, PT_ERR_INVALID, "pt_upload_bvh: " + perr);
     ptscene::refine(T, (uint32_t)c->opt_leaf_max);
     ptscene::Output O;
-    ptscene::emit(T, PT_MAX_TOP, O);
+    ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
     const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
     if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
 
@@ -267,6 +273,7 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
+    c->records_woop = c->opt_tri_test == 1;
     c->wide_root = O.wide_root_f4;
     c->wide_top_layout = O.n_top_wide;
     c->wide_depth = O.depth_wide;
@@ -374,11 +381,17 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     P.sc.stack_n = lstk;
     // the wide walk pushes up to three entries per level
     int walk = c->opt_walk;
-    if (walk == 2 && (!c->has_bvh || 3 * c->wide_depth + 2 > (uint32_t)PT_STACK_CAP)) walk = 1;
+    const bool wide_ok = c->has_bvh && 3 * c->wide_depth + 2 <= (uint32_t)PT_STACK_CAP;
+    if (c->has_bvh && c->records_woop) {
+        if (!wide_ok) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: Woop records need the wide walk and this tree is too deep for it");
+        walk = 3;  // Woop records are only understood by the wide walk
+    } else if (walk == 2 && !wide_ok) {
+        walk = 1;
+    }
     P.sc.wide_root = (int)c->wide_root;
-    P.sc.top_base = walk == 2 ? (int)c->wide_root : 0;
-    P.sc.n_top = c->has_bvh ? (int)std::min<uint32_t>((uint32_t)c->opt_top, walk == 2 ? c->wide_top_layout : c->n_top_layout) : 0;
-    if (walk == 1) P.sc.n_top = 0;  // the binary unified-step walk reads every item from memory
+    P.sc.top_base = walk >= 2 ? (int)c->wide_root : 0;
+    P.sc.n_top = c->has_bvh ? (int)std::min<uint32_t>((uint32_t)c->opt_top, walk >= 2 ? c->wide_top_layout : c->n_top_layout) : 0;
+    if (walk >= 1) P.sc.n_top = 0;  // only the while-while walk reads the LDS mirror
     size_t lds = lds_bytes(P.sc.n_top, lstk, PT_BLOCK);
     while (lds > 160 * 1024 && P.sc.n_top > 0) {  // deep tree: give the LDS to the stack first
         P.sc.n_top /= 2;
@@ -411,7 +424,8 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     } while (0)
 #define PT_LAUNCH_ALG(COUNT, OCC, LSTK)                   \
     do {                                                  \
-        if (walk == 2) PT_LAUNCH(COUNT, OCC, LSTK, 2);    \
+        if (walk == 3) PT_LAUNCH(COUNT, OCC, LSTK, 3);    \
+        else if (walk == 2) PT_LAUNCH(COUNT, OCC, LSTK, 2); \
         else if (walk == 1) PT_LAUNCH(COUNT, OCC, LSTK, 1); \
         else PT_LAUNCH(COUNT, OCC, LSTK, 0);              \
     } while (0)
@@ -440,6 +454,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
 int pt_trace_rays(pt_ctx* c, const float* rays_dev, size_t n, int cull, float* t_dev, int32_t* tri_dev, float* normal_dev) {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
     if (!c->has_bvh) return fail(c, PT_ERR_NO_SCENE, "pt_trace_rays: no BVH uploaded");
+    if (c->records_woop) return fail(c, PT_ERR_UNSUPPORTED, "pt_trace_rays: the ray-batch kernel reads Moller-Trumbore records (upload with PT_OPT_TRI_TEST 0)");
     if (n == 0) return PT_OK;
     if (!rays_dev || !t_dev || !tri_dev) return fail(c, PT_ERR_INVALID, "pt_trace_rays: null argument");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -85,6 +85,11 @@ enum {
                                  reference), 1 = unified-step over the binary tree,
                                  2 = wide (default): unified-step over a 4-way tree with
                                  8-bit outward-rounded boxes; all three report the same hits  */
+    PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
+                                 for Moller-Trumbore, what the reference kernel runs
+                                 (cudaUtils.h:135-172; default, bit-exact vs the oracle);
+                                 1 = Woop affine rows (north_star; CudaBVH.cpp:274-305 done
+                                 right), tolerance-class parity, wide walk only               */
     PT_OPT_LEAF_MAX = 9       /* leaves holding more triangle references than this are split
                                  at the next pt_upload_bvh (0 = keep the producer's leaves;
                                  default 2)                                                   */

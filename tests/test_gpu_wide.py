@@ -126,3 +126,47 @@ def test_config5_open_scene_4096_tile_split(ptw):
     print(f"config5 4096^2 open scene: segments {cnt['rays']}, differing pixels {n_diff}")
     assert l2(whole, ref) < 1e-3
     assert n_diff <= 64
+
+
+# ---------------------------------------------------------------- Woop records (PT_OPT_TRI_TEST 1)
+@pytest.fixture(scope="module")
+def ptwoop():
+    t = g.PathTracer(0)
+    t.set_option(g.OPT_TRI_TEST, 1)
+    yield t
+    t.close()
+
+
+@pytest.mark.parametrize("scene,mat,spp,tol", [("cornell", g.MAT_DIFF, 16, 1e-3), ("cornell_dragon", g.MAT_DIFF, 8, 1e-3),
+                                               ("cornell_dragon", g.MAT_METAL, 16, 1e-3), ("gto_sixteen", g.MAT_REFR, 4, 1e-3),
+                                               ("cornell_dragon", g.MAT_DIFF, 1, 4e-3)])
+def test_woop_records_within_tolerance(ptwoop, scene, mat, spp, tol):
+    """north_star asks for Woop's test; the reference kernel runs Moller-Trumbore and
+    so does the oracle.  Woop's t differs from Moller-Trumbore's in the last bits, so every later
+    bounce is perturbed at the 1e-7 level and about one edge-grazing path per 500k flips to a
+    different surface.  Tolerance-class parity: north_star's per-pixel L2 < 1e-3 holds from a few
+    spp on; a 1-spp frame cannot meet it in general — ONE flipped pixel out of 518 400 is already
+    L2 = 1.3e-3 — so that case bounds the flipped pixels and L2 < 4e-3.  (This is why Woop records
+    are an option and the bit-exact Moller-Trumbore records are the default.)"""
+    W, H = 960, 540
+    _, bvh = bvh_of(scene)
+    sph = g.reference_spheres()
+    cam = golden_camera(W, H)
+    p = g.default_params(W, H, tri_mat=mat)
+    acc, _ = gpu_render(ptwoop, bvh, sph, cam, p, spp)
+    ref, _, _ = orc.render(bvh, sph, cam, p, spp, want_rgba=False)
+    err = l2(acc, ref)
+    big = int((np.abs(acc - ref).max(axis=-1) > 1e-2).sum())
+    print(f"woop {scene} mat {mat} spp {spp}: L2 {err:.3e}, pixels off by > 1e-2: {big} of {W * H}")
+    assert err < tol
+    assert big <= W * H // 10000       # 1e-4 of the pixels
+
+
+def test_woop_ray_batch_is_refused(ptwoop):
+    _, bvh = bvh_of("cornell")
+    ptwoop.upload_bvh(bvh)
+    buf = ptwoop.malloc(1024)
+    with pytest.raises(g.PtError) as e:
+        ptwoop.trace_rays(buf.ptr, 4, True, buf.ptr, buf.ptr, None)
+    assert e.value.code == -5
+    buf.free()
