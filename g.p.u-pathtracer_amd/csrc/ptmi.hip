@@ -50,6 +50,7 @@ struct pt_ctx {
     unsigned int* d_queue = nullptr;   // persistent kernel's work counter
     int n_cu = 0;
     int opt_batch = 40;
+    int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
     int opt_occ = 5;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
@@ -122,7 +123,7 @@ int pt_create(int device, pt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;
     if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
-    if ((e = hipMalloc(&c->d_queue, 64)) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
+    if ((e = hipMalloc(&c->d_queue, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipGetDeviceProperties"); }
     c->n_cu = prop.multiProcessorCount;
@@ -186,6 +187,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
         case PT_OPT_LDS_STACK:
             if (value != 0 && value != 16) return fail(c, PT_ERR_INVALID, "pt_set_option: LDS stack must be 0 (all 72 entries in LDS) or 16 entries");
             c->opt_lstk = value;
+            return PT_OK;
+        case PT_OPT_REFILL:
+            if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: refill must be 1..64");
+            c->opt_refill = value;
             return PT_OK;
         case PT_OPT_BATCH:
             if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: batch must be 1..64");
@@ -400,7 +405,8 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (persistent) {
         P.queue = c->d_queue;
         P.batch = c->opt_batch;
-        HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
+        P.refill = c->opt_refill;
+        HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int), c->stream));
     }
     const int work_blocks = (P.n_tiles * 64 + PT_CHUNK * (PT_BLOCK / 64) - 1) / (PT_CHUNK * (PT_BLOCK / 64));
     // persistent grid: as many blocks as can be resident (no grid-wide wait anywhere, so an

@@ -85,6 +85,8 @@ enum {
                                  reference), 1 = unified-step over the binary tree,
                                  2 = wide (default): unified-step over a 4-way tree with
                                  8-bit outward-rounded boxes; all three report the same hits  */
+    PT_OPT_REFILL = 11,       /* persistent kernel: idle lanes (1..64) that trigger a refill from the
+                                 work queue; default 8                                         */
     PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
                                  for Moller-Trumbore, what the reference kernel runs
                                  (cudaUtils.h:135-172; default, bit-exact vs the oracle);
