@@ -58,6 +58,7 @@ struct KParams {
     unsigned int* queue;
     int batch;
     int refill;   // idle lanes that trigger a refill from the queue
+    int chunk;    // tile-ordered pixel slots per queue fetch (<= PT_CHUNK)
 };
 
 struct Hit {
@@ -813,7 +814,8 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool queue_empty = false;                // wave-uniform
     int shard = (int)(blockIdx.x & (PT_SHARDS - 1));  // wave-uniform: the shard this wave draws from
-    const uint32_t shard_chunks = ((total + PT_CHUNK - 1) / PT_CHUNK + PT_SHARDS - 1) / PT_SHARDS;
+    const uint32_t chunk = (uint32_t)P.chunk;  // slots per fetch: 64, or less when the launch is small
+    const uint32_t shard_chunks = ((total + chunk - 1) / chunk + PT_SHARDS - 1) / PT_SHARDS;
 
     int phase = PH_IDLE;
     uint32_t pix = 0, s_idx = 0;
@@ -850,10 +852,10 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                     uint32_t k = 0;
                     if (lane == 0) k = atomicAdd(P.queue + shard * PT_SHARD_STRIDE, 1u);
                     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                    const uint32_t first = (k * PT_SHARDS + (uint32_t)shard) * PT_CHUNK;  // interleaved chunks
+                    const uint32_t first = (k * PT_SHARDS + (uint32_t)shard) * chunk;  // interleaved chunks
                     if (k < shard_chunks && first < total) {
                         chunk_next = first;
-                        chunk_end = min(first + (uint32_t)PT_CHUNK, total);
+                        chunk_end = min(first + chunk, total);
                         break;
                     }
                     shard = (shard + 1) & (PT_SHARDS - 1);

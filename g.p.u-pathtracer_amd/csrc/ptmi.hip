@@ -408,7 +408,13 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         P.refill = c->opt_refill;
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int), c->stream));
     }
-    const int work_blocks = (P.n_tiles * 64 + PT_CHUNK * (PT_BLOCK / 64) - 1) / (PT_CHUNK * (PT_BLOCK / 64));
+    // queue granularity: 64-slot chunks when the launch has plenty of them per resident wave, smaller
+    // ones for small launches (an eighth of a 1080p frame per GPU is ~4 000 tiles for ~5 000 waves)
+    {
+        const long slots = (long)P.n_tiles * 64, waves = (long)c->n_cu * 20;
+        P.chunk = slots / 64 >= 4 * waves ? 64 : (slots / 32 >= 4 * waves ? 32 : 16);
+    }
+    const int work_blocks = (P.n_tiles * 64 + P.chunk * (PT_BLOCK / 64) - 1) / (P.chunk * (PT_BLOCK / 64));
     // persistent grid: as many blocks as can be resident (no grid-wide wait anywhere, so an
     // over-estimate only means a few late blocks find the queue empty and exit)
 #define PT_LAUNCH(COUNT, OCC, LSTK, ALG)                                                                         \
