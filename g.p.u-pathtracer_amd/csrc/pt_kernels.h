@@ -59,6 +59,10 @@ struct KParams {
     int batch;
     int refill;   // idle lanes that trigger a refill from the queue
     int chunk;    // tile-ordered pixel slots per queue fetch (<= PT_CHUNK)
+    // spp > 1: samples are traced as independent work items into `samples` ([spp][H*W][3] floats)
+    // and folded into the running mean afterwards, in order, by k_fold_samples.  The frame's
+    // critical path is then ONE path, not spp paths, and a launch has spp x more parallel work.
+    float* __restrict__ samples;   // nullptr: fold each sample straight into accum (spp == 1)
 };
 
 struct Hit {
@@ -727,7 +731,13 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams
     lds_load_top<PT_BLOCK>(P.sc, s_top);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int tile = blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
+    int tile = blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
+    uint32_t s_only = 0;
+    if (P.samples) {  // one wave per (sample, tile)
+        s_only = (uint32_t)(tile / P.n_tiles);
+        tile -= (int)s_only * P.n_tiles;
+        if (s_only >= P.spp) return;
+    }
     int tx, ty;
     if (!pt_tile_coords(P, tile, tx, ty)) return;
     const int px = tx * PT_TILE + (lane & 7), py = ty * PT_TILE + (lane >> 3);
@@ -740,18 +750,26 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams
     tc.inner = tc.tris = tc.leaves = 0;
     uint32_t n_rays = 0, n_hits = 0;
 
-    float* acc = P.accum + 3 * pix;
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
-    for (uint32_t s = 0; s < P.spp; s++) {
-        const v3 col = pt_get_sample<COUNT, ALG>(P, px, py, pix, P.frame + s, stk, s_top, tc, n_rays, n_hits);
-        pt_accumulate(ax, ay, az, col, P.sample_index + s);
+    uint32_t n_done = P.spp;
+    if (P.samples) {
+        const v3 col = pt_get_sample<COUNT, ALG>(P, px, py, pix, P.frame + s_only, stk, s_top, tc, n_rays, n_hits);
+        float* dst = P.samples + 3 * ((size_t)s_only * (size_t)P.W * (size_t)P.H + (size_t)pix);
+        dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+        n_done = 1;
+    } else {
+        float* acc = P.accum + 3 * pix;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
+        for (uint32_t s = 0; s < P.spp; s++) {
+            const v3 col = pt_get_sample<COUNT, ALG>(P, px, py, pix, P.frame + s, stk, s_top, tc, n_rays, n_hits);
+            pt_accumulate(ax, ay, az, col, P.sample_index + s);
+        }
+        acc[0] = ax; acc[1] = ay; acc[2] = az;
+        if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
     }
-    acc[0] = ax; acc[1] = ay; acc[2] = az;
-    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
     if (COUNT) {
         const uint32_t a = wave_sum_u32(n_rays), b = wave_sum_u32(tc.inner), c = wave_sum_u32(tc.tris);
-        const uint32_t dd = wave_sum_u32(tc.leaves), e = wave_sum_u32(n_hits), f = wave_sum_u32(P.spp);
+        const uint32_t dd = wave_sum_u32(tc.leaves), e = wave_sum_u32(n_hits), f = wave_sum_u32(n_done);
         if (__ffsll((long long)__ballot(1)) - 1 == lane) {
             atomicAdd(&P.counters[0], (unsigned long long)a);
             atomicAdd(&P.counters[1], (unsigned long long)b);
@@ -809,7 +827,8 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
     TravOverflow<LSTK> stk_ovf;
     TravStack<LSTK, PT_BLOCK> stk(__builtin_amdgcn_readfirstlane(16 * P.sc.n_top + (tid & ~63)), stk_ovf);
     const bool cull = P.cull != 0;
-    const uint32_t total = (uint32_t)P.n_tiles * 64u;
+    const uint32_t slots_per_sample = (uint32_t)P.n_tiles * 64u;
+    const uint32_t total = slots_per_sample * (P.samples ? P.spp : 1u);
 
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool queue_empty = false;                // wave-uniform
@@ -867,16 +886,21 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             if (phase == PH_IDLE) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (rank < take) {
-                    const uint32_t q = chunk_next + rank;
+                    uint32_t q = chunk_next + rank;
+                    uint32_t s_first = 0;
+                    if (P.samples) {  // sample-major slots: [sample][tile][lane]
+                        s_first = q / slots_per_sample;
+                        q -= s_first * slots_per_sample;
+                    }
                     int tx, ty;
                     if (pt_tile_coords(P, (int)(q >> 6), tx, ty)) {
                         px = tx * PT_TILE + (int)(q & 7u);
                         py = ty * PT_TILE + (int)((q >> 3) & 7u);
                         if (px < P.W && py < P.H) {  // tracer.cu:358
                             pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
-                            s_idx = 0;
+                            s_idx = s_first;
                             ax = ay = az = 0.f;
-                            if (P.sample_index != 1) {
+                            if (!P.samples && P.sample_index != 1) {
                                 const float* acc = P.accum + 3 * (size_t)pix;
                                 ax = acc[0]; ay = acc[1]; az = acc[2];
                             }
@@ -931,6 +955,11 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                     trav_begin(ts, ps.o, ps.d, stk, ALG >= 2 ? P.sc.wide_root : 0);
                     phase = PH_TRAV;
                 }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
+            } else if (P.samples) {
+                float* dst = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+                dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+                if (COUNT) n_paths++;
+                phase = PH_IDLE;
             } else {
                 pt_accumulate(ax, ay, az, col, P.sample_index + s_idx);
                 if (COUNT) n_paths++;
@@ -961,4 +990,27 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             atomicAdd(&P.counters[5], (unsigned long long)f);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Folds the spp sample colours of every owned pixel into the running mean, in sample order,
+// with the reference's per-frame clamp (tracer.cu:386-391) and packs the display word
+// (:394-398): exactly what spp consecutive single-sample launches do to the accumulator.
+__global__ void __launch_bounds__(256) k_fold_samples(const KParams P) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int tx, ty;
+    if (!pt_tile_coords(P, tile, tx, ty)) return;
+    const int px = tx * PT_TILE + (lane & 7), py = ty * PT_TILE + (lane >> 3);
+    if (px >= P.W || py >= P.H) return;
+    const size_t pix = (size_t)py * (size_t)P.W + (size_t)px, plane = (size_t)P.W * (size_t)P.H;
+    float* acc = P.accum + 3 * pix;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
+    for (uint32_t s = 0; s < P.spp; s++) {
+        const float* c = P.samples + 3 * (s * plane + pix);
+        pt_accumulate(ax, ay, az, V3(c[0], c[1], c[2]), P.sample_index + s);
+    }
+    acc[0] = ax; acc[1] = ay; acc[2] = az;
+    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
 }

@@ -48,6 +48,8 @@ struct pt_ctx {
     // measurement
     unsigned long long* d_counters = nullptr;
     unsigned int* d_queue = nullptr;   // persistent kernel's work counter
+    float* d_samples = nullptr;        // [spp][H*W][3] sample colours of a multi-sample call
+    size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 40;
     int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
@@ -141,6 +143,7 @@ int pt_destroy(pt_ctx* c) {
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_queue);
+    (void)hipFree(c->d_samples);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -375,7 +378,23 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     }
     if (P.n_tiles <= 0) return PT_OK;
     const int waves_per_block = PT_BLOCK / 64;
-    const int blocks = (P.n_tiles + waves_per_block - 1) / waves_per_block;
+    // spp > 1: trace the samples as independent work items, fold them afterwards (k_fold_samples)
+    P.samples = nullptr;
+    if (spp > 1) {
+        const size_t need = (size_t)spp * (size_t)p->width * (size_t)p->height * 3 * sizeof(float);
+        if (need > c->samples_bytes) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_samples);
+            c->d_samples = nullptr;
+            c->samples_bytes = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->d_samples, need));
+            c->samples_bytes = need;
+        }
+        P.samples = c->d_samples;
+    }
+    if ((uint64_t)P.n_tiles * 64u * (uint64_t)spp >= (1ull << 31)) return fail(c, PT_ERR_INVALID, "pt_render: width*height*spp too large for one call (split the samples over several calls)");
+    const int work_tiles = P.n_tiles * (P.samples ? (int)spp : 1);
+    const int blocks = (work_tiles + waves_per_block - 1) / waves_per_block;
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -411,10 +430,10 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     // queue granularity: 64-slot chunks when the launch has plenty of them per resident wave, smaller
     // ones for small launches (an eighth of a 1080p frame per GPU is ~4 000 tiles for ~5 000 waves)
     {
-        const long slots = (long)P.n_tiles * 64, waves = (long)c->n_cu * 20;
+        const long slots = (long)work_tiles * 64, waves = (long)c->n_cu * 20;
         P.chunk = slots / 64 >= 4 * waves ? 64 : (slots / 32 >= 4 * waves ? 32 : 16);
     }
-    const int work_blocks = (P.n_tiles * 64 + P.chunk * (PT_BLOCK / 64) - 1) / (P.chunk * (PT_BLOCK / 64));
+    const int work_blocks = (int)(((long)work_tiles * 64 + P.chunk * (PT_BLOCK / 64) - 1) / (P.chunk * (PT_BLOCK / 64)));
     // persistent grid: as many blocks as can be resident (no grid-wide wait anywhere, so an
     // over-estimate only means a few late blocks find the queue empty and exit)
 #define PT_LAUNCH(COUNT, OCC, LSTK, ALG)                                                                         \
@@ -458,6 +477,10 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
 #undef PT_LAUNCH_ALG
 #undef PT_LAUNCH_OCC
 #undef PT_LAUNCH
+    if (P.samples) {
+        HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(k_fold_samples, dim3((P.n_tiles + 3) / 4), dim3(256), 0, c->stream, P);
+    }
     HIP_TRY(c, hipGetLastError());
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
     return PT_OK;
