@@ -8,9 +8,13 @@ cornell_dragon 1920x1080, depth 4, reference sphere room, 1/2/4/8 GPUs.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one progressive frame: one pass of the hot path (pt_render through the C ABI,
-`--spp` samples per pixel, default 1 like the reference's one launch per displayed frame,
-BasicScene.cpp:404) over the whole 1920x1080 framebuffer.  With N > 1 the framebuffer is
+A "step" is one progressive frame: one pass of the hot path — ONE pt_render call through the C
+ABI, `render(accum, bvh, camera, spp)` of BASELINE.json — folding `--spp` samples per pixel
+(default 16; BASELINE's config 5 uses 8) into the whole 1920x1080 framebuffer.  The reference
+launches one sample per displayed frame (BasicScene.cpp:404); a call with spp = S equals S such
+launches bit for bit, but traces the S samples as independent work items, which is what gives
+eight GPUs enough parallel work on an eighth of the frame each (1 spp: 0.47 ms for an eighth of
+a 1.13 ms frame; 8 spp: 1.29 of 7.10 ms).  With N > 1 the framebuffer is
 tile-split into interleaved 8-row stripes (stripe s belongs to rank s % N), every rank
 renders its stripes of the SAME frame with the scene replicated, and the display words are
 gathered on rank 0 with RCCL each step (the reference copies the frame to the display
@@ -47,7 +51,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=4)
-    ap.add_argument("--spp", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=16,
+                    help="samples per pixel folded by ONE pt_render call = one step (render(accum, bvh, camera, spp))")
     ap.add_argument("--mat", default="diff", choices=["diff", "metal", "spec", "refr"])
     ap.add_argument("--no-spheres", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="PT_KERNEL_* (0 = auto)")
@@ -77,7 +82,7 @@ def cpu_baseline(g, bvh, sph, cam, params, first_frame, n_frames, spp):
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
     return {"value": cnt["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} frame(s) x {spp} spp of the bench workload ({p.width}x{p.height}, depth {p.depth}), "
+            "sample": f"{n_frames} step(s) x {spp} spp of the bench workload ({p.width}x{p.height}, depth {p.depth}), "
                       f"{cnt['rays']} ray segments in {dt:.2f} s, oracle/pt_oracle.c with OpenMP"}, cnt, acc
 
 

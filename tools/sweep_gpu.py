@@ -14,6 +14,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--mat", type=int, default=0)
+ap.add_argument("--spp", type=int, default=1)
 ap.add_argument("--no-spheres", action="store_true")
 ap.add_argument("--bvh", default="", help="builder overrides, e.g. split_alpha=1e-5,sah_tri_cost=2")
 ap.add_argument("--leaf-max", type=int, default=2)
@@ -55,9 +56,9 @@ for r in range(a.rounds + 1):
         t0 = time.perf_counter()
         for f in range(a.frames):
             p = g.default_params(W, H, tri_mat=a.mat)
-            p.frame, p.sample_index = f, 1 + f
+            p.frame, p.sample_index = f * a.spp, 1 + f * a.spp
             p.flags = g.FLAG_WRITE_RGBA
-            pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, 1)
+            pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, a.spp)
         pt.sync()
         dt = (time.perf_counter() - t0) / a.frames
         if r > 0:
@@ -65,4 +66,4 @@ for r in range(a.rounds + 1):
 print(f"scene {a.scene} {W}x{H} mat {a.mat} spheres {not a.no_spheres}: ms/frame (median, min) and Mrays/s at median (closed-scene bound)")
 for name, v in res.items():
     med, mn = float(np.median(v)), float(np.min(v))
-    print(f"  {name:26s} median {med:7.3f} ms  min {mn:7.3f} ms   {W * H * 4 / med / 1e3:8.1f} Mrays/s")
+    print(f"  {name:26s} median {med:7.3f} ms  min {mn:7.3f} ms   {W * H * 4 * a.spp / med / 1e3:8.1f} Mrays/s")
