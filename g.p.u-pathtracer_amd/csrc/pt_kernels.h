@@ -58,6 +58,7 @@ struct KParams {
     unsigned int* queue;
     int batch;
     int refill;   // idle lanes that trigger a refill from the queue
+    int vote_node, vote_rec;  // postponed-leaf walk: node step when n_node*vote_node >= n_rec*vote_rec
     int chunk;    // tile-ordered pixel slots per queue fetch (<= PT_CHUNK)
     // spp > 1: samples are traced as independent work items into `samples` ([spp][H*W][3] floats)
     // and folded into the running mean afterwards, in order, by k_fold_samples.  The frame's
@@ -73,6 +74,9 @@ struct Hit {
 
 struct TravCount {
     uint32_t inner, tris, leaves;
+    // wave-level schedule statistics (instrumented launches of the wide walk only; identical in
+    // every lane): iterations spent in node / record steps and the lanes active in them
+    uint32_t it_node, act_node, it_rec, act_rec;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -367,6 +371,10 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         const int n_node = __popcll(__ballot(is_node));
         // a record step costs about half a node step: run whichever advances more lanes per instruction
         const bool node_phase = n_node >= 2 * (n_live - n_node);
+        if (COUNT) {
+            if (node_phase) { tc.it_node++; tc.act_node += n_node; }
+            else { tc.it_rec++; tc.act_rec += n_live - n_node; }
+        }
         if (!live || is_node != node_phase) continue;
         const int a = cur >= 0 ? cur : ~cur;
         float4 q0, q1, q2;
@@ -476,6 +484,113 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
     }
     s.node = cur; s.sp = sp; s.h = h;
     return cur == PT_SENTINEL;
+}
+
+// Wide walk with ONE postponed leaf per lane (Aila-Laine's trick, restated for the phase vote):
+// a lane that reaches a leaf parks it in `pend` and goes on with the next stack entry, so it can
+// take part in node steps AND in record steps; it only waits when it holds a parked leaf and
+// reaches a second one.  The closest hit is order independent (every pruning test uses a valid
+// upper bound h.t, equal-t ties go to the smaller id), so the result is bit-identical to the
+// other walks; parking a leaf only delays the tightening of h.t by a few node steps.
+template <bool COUNT, bool DYN, class STK>
+__device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                                   TravCount& tc, int n_dead, int batch, int vote_node, int vote_rec) {
+    int cur = s.node, sp = s.sp, pend = s.leaf;  // pend: ~address of the next record of the parked leaf, 0 = none
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    for (;;) {
+        const bool has_node = (unsigned)cur < (unsigned)PT_SENTINEL;
+        const bool has_rec = pend != 0;
+        const int n_live = __popcll(__ballot(has_node || has_rec));
+        if (n_live == 0) break;
+        if (DYN && 64 - n_live - n_dead >= batch) break;  // enough lanes wait for service
+        const int n_node = __popcll(__ballot(has_node));
+        const int n_rec = __popcll(__ballot(has_rec));
+        const bool node_phase = n_node * vote_node >= n_rec * vote_rec;
+        if (COUNT) {
+            if (node_phase) { tc.it_node++; tc.act_node += n_node; }
+            else { tc.it_rec++; tc.act_rec += n_rec; }
+        }
+        if (node_phase) {
+            if (!has_node) continue;
+            const int a = cur;
+            const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2], q3 = sc.nodes[a + 3];
+            int l2 = __float_as_int(q3.x), l3 = __float_as_int(q3.y);
+            asm volatile("" : "+v"(l2), "+v"(l3));
+            if (COUNT) tc.inner++;
+            const uint32_t meta = __float_as_uint(q0.w);
+            const float sx = __uint_as_float((meta & 0xffu) << 23) * idx;
+            const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy;
+            const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+            const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
+            const int nch = (int)(meta >> 24);
+            const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
+            const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
+            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+            const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx;
+            const uint32_t ny = py ? qly : qhy, fy = py ? qhy : qly;
+            const uint32_t nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
+            const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
+            uint32_t key[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
+                const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
+                const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
+                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
+                const bool hit = (k < nch) && (tmin <= tmax);
+                key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
+            }
+#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+#define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
+            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
+            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
+            if (key[1] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[1])); }
+            if (key[0] != 0xffffffffu) {
+                cur = PT_LINK(key[0]);
+            } else {
+                cur = stk.get(sp);
+                sp--;
+            }
+#undef PT_LINK
+            if (COUNT && cur < 0) tc.leaves++;
+            if (cur < 0 && pend == 0) {  // park the leaf, go on with the next entry
+                pend = cur;
+                cur = stk.get(sp);
+                sp--;
+                if (COUNT && cur < 0) tc.leaves++;
+            }
+        } else {
+            if (!has_rec) continue;
+            const int a = ~pend;
+            const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2];
+            if (COUNT) tc.tris++;
+            const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+            const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+            const int id = __float_as_int(q0.w);
+            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                h.t = t;
+                h.tri = id;
+                const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
+                h.n = V3(q3.x, q3.y, q3.z);
+            }
+            if (__float_as_int(q1.w) != 0) {  // last record of the leaf
+                pend = 0;
+                if (cur < 0) {  // a second leaf was waiting in cur
+                    pend = cur;
+                    cur = stk.get(sp);
+                    sp--;
+                }
+            } else {
+                pend -= 4;  // ~(a + 4)
+            }
+        }
+    }
+    s.node = cur; s.sp = sp; s.h = h; s.leaf = pend;
+    return cur == PT_SENTINEL && pend == 0;
 }
 
 template <bool COUNT, bool TOP, class STK>
@@ -850,9 +965,12 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
 
     TravCount tc;
     tc.inner = tc.tris = tc.leaves = 0;
+    tc.it_node = tc.act_node = tc.it_rec = tc.act_rec = 0;
     uint32_t n_rays = 0, n_hits = 0, n_paths = 0;
+    uint32_t it_begin = 0, act_begin = 0, it_shade = 0, act_shade = 0, it_loop = 0;  // COUNT only
 
     for (;;) {
+        if (COUNT) it_loop++;
         // ---- A. refill idle lanes (all 64 lanes are converged here)
         const unsigned long long idle = __ballot(phase == PH_IDLE);
         const int n_idle = __popcll(idle);
@@ -914,6 +1032,10 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         }
 
         // ---- C0. lanes that start a sample: camera ray, then walk (or straight to shading)
+        if (COUNT) {
+            const int nb = __popcll(__ballot(phase == PH_SHADE && ps.depth == 0xffffffffu));
+            if (nb) { it_begin++; act_begin += nb; }
+        }
         if (phase == PH_SHADE && ps.depth == 0xffffffffu) {
             path_begin(P, px, py, (uint64_t)pix, P.frame + s_idx, ps);
             if (P.depth == 0) {
@@ -933,7 +1055,8 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         {
             const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
             if (phase == PH_TRAV) {
-                const bool fin = (ALG >= 2)   ? trav_run_wide<COUNT, true, false, ALG == 3>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                const bool fin = (ALG == 4)   ? trav_run_wide_pend<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, P.vote_node, P.vote_rec)
+                                 : (ALG >= 2) ? trav_run_wide<COUNT, true, false, ALG == 3>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                  : (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                               : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
                 if (fin) phase = PH_SHADE;
@@ -941,6 +1064,10 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
         }
 
         // ---- C. shade finished segments
+        if (COUNT) {
+            const int nb = __popcll(__ballot(phase == PH_SHADE && ps.depth != 0xffffffffu));
+            if (nb) { it_shade++; act_shade += nb; }
+        }
         if (phase == PH_SHADE && ps.depth != 0xffffffffu) {
             v3 col = V3(0.f, 0.f, 0.f);
             bool done;
@@ -988,6 +1115,16 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             atomicAdd(&P.counters[3], (unsigned long long)dd);
             atomicAdd(&P.counters[4], (unsigned long long)e);
             atomicAdd(&P.counters[5], (unsigned long long)f);
+            // schedule statistics, one contribution per wave (pt_get_wave_stats)
+            atomicAdd(&P.counters[6], (unsigned long long)tc.it_node);
+            atomicAdd(&P.counters[7], (unsigned long long)tc.act_node);
+            atomicAdd(&P.counters[8], (unsigned long long)tc.it_rec);
+            atomicAdd(&P.counters[9], (unsigned long long)tc.act_rec);
+            atomicAdd(&P.counters[10], (unsigned long long)it_shade);
+            atomicAdd(&P.counters[11], (unsigned long long)act_shade);
+            atomicAdd(&P.counters[12], (unsigned long long)it_begin);
+            atomicAdd(&P.counters[13], (unsigned long long)act_begin);
+            atomicAdd(&P.counters[14], (unsigned long long)it_loop);
         }
     }
 }

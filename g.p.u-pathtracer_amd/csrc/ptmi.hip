@@ -52,6 +52,7 @@ struct pt_ctx {
     size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 40;
+    int opt_vote_node = 3, opt_vote_rec = 2;
     int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
     int opt_occ = 5;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
@@ -124,7 +125,7 @@ int pt_create(int device, pt_ctx** out) {
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;
-    if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
+    if ((e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
     if ((e = hipMalloc(&c->d_queue, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipGetDeviceProperties"); }
@@ -184,8 +185,13 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             c->opt_leaf_max = value;   // takes effect at the next pt_upload_bvh
             return PT_OK;
         case PT_OPT_WALK:
-            if (value < 0 || value > 2) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while), 1 (unified-step) or 2 (wide)");
+            if (value < 0 || value > 4 || value == 3) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while), 1 (unified-step), 2 (wide) or 4 (wide, postponed leaf)");
             c->opt_walk = value;
+            return PT_OK;
+        case PT_OPT_VOTE_NODE:
+        case PT_OPT_VOTE_REC:
+            if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: vote weight must be 1..64");
+            (option == PT_OPT_VOTE_NODE ? c->opt_vote_node : c->opt_vote_rec) = value;
             return PT_OK;
         case PT_OPT_LDS_STACK:
             if (value != 0 && value != 16) return fail(c, PT_ERR_INVALID, "pt_set_option: LDS stack must be 0 (all 72 entries in LDS) or 16 entries");
@@ -396,7 +402,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     const int work_tiles = P.n_tiles * (P.samples ? (int)spp : 1);
     const int blocks = (work_tiles + waves_per_block - 1) / waves_per_block;
 
-    if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     const bool persistent = c->opt_kernel == PT_KERNEL_PERSISTENT || c->opt_kernel == PT_KERNEL_AUTO;
     const int need = stack_for_depth(c->has_bvh ? c->max_depth : 0);
@@ -409,7 +415,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (c->has_bvh && c->records_woop) {
         if (!wide_ok) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: Woop records need the wide walk and this tree is too deep for it");
         walk = 3;  // Woop records are only understood by the wide walk
-    } else if (walk == 2 && !wide_ok) {
+    } else if ((walk == 2 || walk == 4) && !wide_ok) {
         walk = 1;
     }
     P.sc.wide_root = (int)c->wide_root;
@@ -424,7 +430,11 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (persistent) {
         P.queue = c->d_queue;
         P.batch = c->opt_batch;
-        P.refill = c->opt_refill;
+        // refill <= batch, or a wave can spin: the walk returns at once because `batch` lanes wait,
+        // none of them has anything to shade and the idle ones are too few to trigger a refill
+        P.refill = c->opt_refill < c->opt_batch ? c->opt_refill : c->opt_batch;
+        P.vote_node = c->opt_vote_node;
+        P.vote_rec = c->opt_vote_rec;
         HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int), c->stream));
     }
     // queue granularity: 64-slot chunks when the launch has plenty of them per resident wave, smaller
@@ -455,7 +465,8 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     } while (0)
 #define PT_LAUNCH_ALG(COUNT, OCC, LSTK)                   \
     do {                                                  \
-        if (walk == 3) PT_LAUNCH(COUNT, OCC, LSTK, 3);    \
+        if (walk == 4) PT_LAUNCH(COUNT, OCC, LSTK, 4);    \
+        else if (walk == 3) PT_LAUNCH(COUNT, OCC, LSTK, 3); \
         else if (walk == 2) PT_LAUNCH(COUNT, OCC, LSTK, 2); \
         else if (walk == 1) PT_LAUNCH(COUNT, OCC, LSTK, 1); \
         else PT_LAUNCH(COUNT, OCC, LSTK, 0);              \
@@ -519,6 +530,16 @@ int pt_get_counters(pt_ctx* c, pt_counters* out) {
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->rays = h[0]; out->inner = h[1]; out->tris = h[2]; out->leaves = h[3]; out->hits = h[4]; out->paths = h[5];
+    return PT_OK;
+}
+
+int pt_get_wave_stats(pt_ctx* c, uint64_t* out, int n) {
+    if (!c || !out || n < 0) return fail(c, PT_ERR_INVALID, "pt_get_wave_stats: bad argument");
+    unsigned long long h[16];
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n && i < PT_WAVE_STATS; i++) out[i] = h[6 + i];
     return PT_OK;
 }
 

@@ -132,6 +132,12 @@ class PathTracer:
         self._check(self._lib.pt_get_counters(self._ctx, C.byref(c)))
         return {f: getattr(c, f) for f, _ in Counters._fields_}
 
+    def wave_stats(self):
+        out = (C.c_uint64 * 9)()
+        self._check(self._lib.pt_get_wave_stats(self._ctx, out, 9))
+        names = ("it_node", "act_node", "it_rec", "act_rec", "it_shade", "act_shade", "it_begin", "act_begin", "it_loop")
+        return dict(zip(names, [int(v) for v in out]))
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self._check(self._lib.pt_last_kernel_ms(self._ctx, C.byref(ms)))

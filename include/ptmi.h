@@ -84,9 +84,13 @@ enum {
     PT_OPT_WALK = 8,          /* closest-hit walk: 0 = while-while (Aila-Laine order, as the
                                  reference), 1 = unified-step over the binary tree,
                                  2 = wide (default): unified-step over a 4-way tree with
-                                 8-bit outward-rounded boxes; all three report the same hits  */
+                                 8-bit outward-rounded boxes; 4 = wide with one postponed leaf
+                                 per lane (persistent kernel); all report the same hits         */
     PT_OPT_REFILL = 11,       /* persistent kernel: idle lanes (1..64) that trigger a refill from the
-                                 work queue; default 8                                         */
+                                 work queue; default 8; values above PT_OPT_BATCH are
+                                 clamped to it (a wave must always have work to go to)          */
+    PT_OPT_VOTE_NODE = 12,    /* walk 4: a wave runs a node step when                              */
+    PT_OPT_VOTE_REC = 13,     /*   lanes_with_node * VOTE_NODE >= lanes_with_record * VOTE_REC (3, 2) */
     PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
                                  for Moller-Trumbore, what the reference kernel runs
                                  (cudaUtils.h:135-172; default, bit-exact vs the oracle);
@@ -209,6 +213,13 @@ int pt_trace_rays(pt_ctx* ctx, const float* rays_dev, size_t n_rays, int cull_ba
 
 /* ---- measurement --------------------------------------------------------------- */
 int pt_get_counters(pt_ctx* ctx, pt_counters* out);
+/* Schedule statistics of the last instrumented launch of the persistent wide walk
+ * (PT_OPT_COUNTERS=1), summed over waves; up to PT_WAVE_STATS values:
+ * [0] node-step iterations  [1] lanes active in them  [2] record-step iterations  [3] lanes
+ * [4] shading passes        [5] lanes                 [6] path-start passes       [7] lanes
+ * [8] outer-loop iterations.  A wave-iteration with all 64 lanes active is 100 % use. */
+#define PT_WAVE_STATS 9
+int pt_get_wave_stats(pt_ctx* ctx, uint64_t* out, int n);
 int pt_last_kernel_ms(pt_ctx* ctx, float* ms_out);   /* needs PT_OPT_TIMING=1 */
 int pt_scene_info(pt_ctx* ctx, uint64_t* n_inner, uint64_t* n_tri_refs,
                   uint64_t* n_leaves, uint32_t* max_depth, uint64_t* device_bytes);

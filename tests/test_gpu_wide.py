@@ -18,11 +18,12 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module", params=[g.KERNEL_PERSISTENT, g.KERNEL_MEGA_BVH2], ids=["persistent-wide", "mega-wide"])
+@pytest.fixture(scope="module", params=[(g.KERNEL_PERSISTENT, 2), (g.KERNEL_MEGA_BVH2, 2), (g.KERNEL_PERSISTENT, 4)],
+                ids=["persistent-wide", "mega-wide", "persistent-wide-postponed-leaf"])
 def ptw(request):
     t = g.PathTracer(0)
-    t.set_option(g.OPT_KERNEL, request.param)
-    t.set_option(g.OPT_WALK, 2)
+    t.set_option(g.OPT_KERNEL, request.param[0])
+    t.set_option(g.OPT_WALK, request.param[1])
     yield t
     t.close()
 

@@ -19,7 +19,7 @@ ap.add_argument("--no-spheres", action="store_true")
 ap.add_argument("--bvh", default="", help="builder overrides, e.g. split_alpha=1e-5,sah_tri_cost=2")
 ap.add_argument("--leaf-max", type=int, default=2)
 ap.add_argument("--variants", default="mega::64:8:16:0,mega::0:8:16:1,mega::0:6:16:1,mega::0:4:16:1,persist:16:0:8:16:1,persist:16:0:6:16:1,persist:16:0:4:16:1,persist:8:0:8:16:1,persist:32:0:8:16:1,persist:16:64:8:16:0",
-                help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack[:walk[:refill]]]]]]")
+                help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack[:walk[:refill[:vote_node[:vote_rec]]]]]]]]")
 a = ap.parse_args()
 
 W, H = a.width, a.height
@@ -38,13 +38,14 @@ cam = g.default_camera(W, H)
 acc, rgba = pt.alloc_frame(W, H)
 variants = []
 for v in a.variants.split(","):
-    parts = v.split(":") + ["", "", "", "", "", ""]
+    parts = v.split(":") + ["", "", "", "", "", "", "", ""]
     variants.append((v, {"mega": g.KERNEL_MEGA_BVH2, "persist": g.KERNEL_PERSISTENT, "wide": g.KERNEL_MEGA_WIDE}[parts[0]],
                      int(parts[1]) if parts[1] else 16, int(parts[2]) if parts[2] else 64,
-                     int(parts[3]) if parts[3] else 5, int(parts[4]) if parts[4] else 16, int(parts[5]) if parts[5] else 2, int(parts[6]) if parts[6] else 16))
+                     int(parts[3]) if parts[3] else 5, int(parts[4]) if parts[4] else 16, int(parts[5]) if parts[5] else 2, int(parts[6]) if parts[6] else 8,
+                     int(parts[7]) if parts[7] else 3, int(parts[8]) if parts[8] else 2))
 res = {v[0]: [] for v in variants}
 for r in range(a.rounds + 1):
-    for name, k, batch, top, occ, lstk, walk, refill in variants:
+    for name, k, batch, top, occ, lstk, walk, refill, vn, vr in variants:
         pt.set_option(g.OPT_KERNEL, k)
         pt.set_option(g.OPT_BATCH, batch)
         pt.set_option(g.OPT_TOP_NODES, top)
@@ -52,6 +53,8 @@ for r in range(a.rounds + 1):
         pt.set_option(g.OPT_LDS_STACK, lstk)
         pt.set_option(g.OPT_WALK, walk)
         pt.set_option(g.OPT_REFILL, refill)
+        pt.set_option(g.OPT_VOTE_NODE, vn)
+        pt.set_option(g.OPT_VOTE_REC, vr)
         pt.sync()
         t0 = time.perf_counter()
         for f in range(a.frames):
