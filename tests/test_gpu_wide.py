@@ -24,6 +24,7 @@ def ptw(request):
     t = g.PathTracer(0)
     t.set_option(g.OPT_KERNEL, request.param[0])
     t.set_option(g.OPT_WALK, request.param[1])
+    t._walk = request.param[1]
     yield t
     t.close()
 
@@ -88,7 +89,7 @@ def test_wide_equals_exact_kernel_on_hits(ptw):
         a_e, _ = gpu_render(ptw, bvh, sph, cam, p, 2)
         c_e = ptw.counters()
     finally:
-        ptw.set_option(g.OPT_WALK, 2)
+        ptw.set_option(g.OPT_WALK, ptw._walk)
         ptw.set_option(g.OPT_COUNTERS, 0)
     print("wide counters", c_w, "exact counters", c_e)
     assert np.any(a_w != a_e, axis=-1).sum() <= 10
