@@ -29,6 +29,11 @@ class Sphere(C.Structure):
                 ("mat", C.c_int32)]
 
 
+class Material(C.Structure):
+    """pt_material — one row of the per-triangle material table (extension, include/ptmi.h)."""
+    _fields_ = [("col", C.c_float * 3), ("emi", C.c_float * 3), ("mat", C.c_int32), ("phong_expo", C.c_float)]
+
+
 class Params(C.Structure):
     """pt_params — scalar part of kernelInfo, GpuPathTracer/CpuStructs.hpp:45-72."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_uint32),
@@ -83,6 +88,7 @@ PTMI_SYMBOLS = [
     ("pt_upload_spheres", _i, [_vp, C.POINTER(Sphere), _sz]),
     ("pt_render", _i, [_vp, _vp, _vp, C.POINTER(Camera), C.POINTER(Params), _u32]),
     ("pt_trace_rays", _i, [_vp, _vp, _sz, _i, _vp, _vp, _vp]),
+    ("pt_upload_tri_materials", _i, [_vp, C.POINTER(Material), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t]),
     ("pt_get_counters", _i, [_vp, C.POINTER(Counters)]),
     ("pt_get_wave_stats", _i, [_vp, C.POINTER(C.c_uint64), _i]),
     ("pt_last_kernel_ms", _i, [_vp, C.POINTER(C.c_float)]),
@@ -102,6 +108,11 @@ PTHOST_SYMBOLS = [
     ("pth_mesh_verts", _vp, [_vp]),
     ("pth_mesh_tris", _vp, [_vp]),
     ("pth_mesh_bounds", None, [_vp, C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
+    ("pth_mesh_save_ptmesh", _i, [_vp, C.c_char_p]),
+    ("pth_mesh_n_materials", _sz, [_vp]),
+    ("pth_mesh_materials", _vp, [_vp]),
+    ("pth_mesh_tri_materials", _vp, [_vp]),
+    ("pth_mesh_set_materials", _i, [_vp, C.POINTER(Material), _sz, _vp]),
     ("pth_mesh_free", None, [_vp]),
     ("pth_bvh_build", _vp, [_vp, C.POINTER(BuildParams)]),
     ("pth_bvh_nodes", _vp, [_vp]),

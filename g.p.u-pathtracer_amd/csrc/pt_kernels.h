@@ -48,6 +48,9 @@ struct KParams {
     int tri_mat;
     float tri_col[3], tri_emi[3], bk[3];
     float air_ior, glass_ior, phong;
+    // per-triangle materials (pt_upload_tri_materials): NULL = the reference's one global material
+    const int* tri_matid;          // [original triangle id] -> row of mat_table
+    const float4* mat_table;       // 2 float4 per material: (col, emi.x) (emi.yz, mat bits, phong)
     uint32_t flags;
     // tile enumeration: tiles_x tiles per tile-row; this launch covers n_tiles tiles taken
     // from the tile-rows this partition owns (stripes of stripe_tr tile-rows, round-robin)
@@ -671,6 +674,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     v3 hitpos = vmadd(d, scene_t, o);
     v3 n, nl, objcol, emit;
     int mat;
+    float phong = P.phong;
     if (geom == 1) {
         const pt_sphere_d& s = P.sc.spheres[sph_id];
         n = vnormalize(vsub(hitpos, V3(s.px, s.py, s.pz)));
@@ -681,9 +685,18 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     } else if (geom == 0) {
         n = vnormalize(h.n);
         nl = n;  // tracer.cu:126-127
-        objcol = V3(P.tri_col[0], P.tri_col[1], P.tri_col[2]);
-        emit = V3(P.tri_emi[0], P.tri_emi[1], P.tri_emi[2]);
-        mat = P.tri_mat;
+        if (P.tri_matid) {  // extension: per-triangle material row
+            const int row = P.tri_matid[h.tri];
+            const float4 m0 = P.mat_table[2 * row], m1 = P.mat_table[2 * row + 1];
+            objcol = V3(m0.x, m0.y, m0.z);
+            emit = V3(m0.w, m1.x, m1.y);
+            mat = __float_as_int(m1.z);
+            phong = m1.w;
+        } else {
+            objcol = V3(P.tri_col[0], P.tri_col[1], P.tri_col[2]);
+            emit = V3(P.tri_emi[0], P.tri_emi[1], P.tri_emi[2]);
+            mat = P.tri_mat;
+        }
     } else {
         col_out = V3(P.bk[0], P.bk[1], P.bk[2]);  // tracer.cu:140-142: unmasked background
         return true;
@@ -739,7 +752,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         const float f1 = pt_rng_next(rng), r2 = pt_rng_next(rng);
         float cphi, sphi;
         pt_sincos2pi(f1, cphi, sphi);
-        const float cosT = pt_pow01(1.0f - r2, 1.0f / (P.phong + 1.0f));
+        const float cosT = pt_pow01(1.0f - r2, 1.0f / (phong + 1.0f));
         const float sinT = sqrtf(1.0f - cosT * cosT);
         const v3 w1 = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
         const v3 ax = ((double)fabsf(w1.x) > 0.1) ? V3(0.f, 1.f, 0.f) : V3(1.f, 0.f, 0.f);

@@ -32,6 +32,10 @@ struct pt_ctx {
     float4* d_nodes = nullptr;
     float4* d_tris = nullptr;
     pt_sphere_d* d_spheres = nullptr;
+    int* d_tri_matid = nullptr;        // pt_upload_tri_materials
+    float4* d_mat_table = nullptr;
+    size_t n_tri_matid = 0;
+    int32_t max_tri_id = -1;           // largest original triangle id of the uploaded BVH
     int n_spheres = 0;
     pt_sphere_d h_spheres[PT_KSPHERES];   // host copy of the first spheres for the kernel-argument block
     uint64_t n_inner = 0, n_refs = 0, n_leaves = 0, scene_bytes = 0;
@@ -142,6 +146,8 @@ int pt_destroy(pt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->d_nodes);  // d_tris aliases it
     (void)hipFree(c->d_spheres);
+    (void)hipFree(c->d_tri_matid);
+    (void)hipFree(c->d_mat_table);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_samples);
@@ -271,6 +277,10 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     std::string perr;
     if (!ptscene::parse(nodes, n_node_vec4, tri_verts, n_tri_vec4, tri_index, T, perr))
         return fail(c, PT_ERR_INVALID, "pt_upload_bvh: " + perr);
+    int32_t max_id = -1;
+    for (const ptscene::Ref& r : T.refs) max_id = std::max(max_id, r.id);
+    if (c->d_tri_matid && (size_t)max_id >= c->n_tri_matid)
+        return fail(c, PT_ERR_INVALID, "pt_upload_bvh: the triangle-material array on this context does not cover this BVH's triangle ids (clear or re-upload it first)");
     ptscene::refine(T, (uint32_t)c->opt_leaf_max);
     ptscene::Output O;
     ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
@@ -301,7 +311,39 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     c->n_leaves = n_leaves;
     c->max_depth = max_depth;
     c->scene_bytes = nb + tb + wb;
+    c->max_tri_id = max_id;
     c->has_bvh = true;
+    return PT_OK;
+}
+
+int pt_upload_tri_materials(pt_ctx* c, const pt_material* table, size_t n_materials, const int32_t* tri_material, size_t n_tris) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_materials == 0) {  // back to the one global material of pt_params
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_tri_matid); c->d_tri_matid = nullptr;
+        (void)hipFree(c->d_mat_table); c->d_mat_table = nullptr;
+        c->n_tri_matid = 0;
+        return PT_OK;
+    }
+    if (!table || !tri_material) return fail(c, PT_ERR_INVALID, "pt_upload_tri_materials: null array");
+    if (n_materials > (1u << 24) || n_tris >= (size_t)0x7fffffff) return fail(c, PT_ERR_INVALID, "pt_upload_tri_materials: table too large");
+    if (c->has_bvh && (size_t)c->max_tri_id >= n_tris && c->max_tri_id >= 0)
+        return fail(c, PT_ERR_INVALID, "pt_upload_tri_materials: n_tris does not cover the triangle ids of the uploaded BVH");
+    for (size_t i = 0; i < n_materials; i++)
+        if (table[i].mat < PT_MAT_DIFF || table[i].mat > PT_MAT_REFR) return fail(c, PT_ERR_INVALID, "pt_upload_tri_materials: bad material type");
+    for (size_t i = 0; i < n_tris; i++)
+        if (tri_material[i] < 0 || (size_t)tri_material[i] >= n_materials) return fail(c, PT_ERR_INVALID, "pt_upload_tri_materials: material index out of range");
+    static_assert(sizeof(pt_material) == 32, "pt_material is two float4 rows");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_tri_matid); c->d_tri_matid = nullptr;
+    (void)hipFree(c->d_mat_table); c->d_mat_table = nullptr;
+    c->n_tri_matid = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_tri_matid, n_tris * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_mat_table, n_materials * sizeof(pt_material)));
+    HIP_TRY(c, hipMemcpy(c->d_tri_matid, tri_material, n_tris * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_mat_table, table, n_materials * sizeof(pt_material), hipMemcpyHostToDevice));
+    c->n_tri_matid = n_tris;
     return PT_OK;
 }
 
@@ -370,6 +412,8 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     P.tri_mat = p->tri_mat;
     for (int i = 0; i < 3; i++) { P.tri_col[i] = p->tri_col[i]; P.tri_emi[i] = p->tri_emi[i]; P.bk[i] = p->bk_color[i]; }
     P.air_ior = p->air_ior; P.glass_ior = p->glass_ior; P.phong = p->phong_expo;
+    P.tri_matid = c->d_tri_matid;
+    P.mat_table = c->d_mat_table;
     P.flags = p->flags;
     P.tiles_x = (p->width + PT_TILE - 1) / PT_TILE;
     P.tile_rows = (p->height + PT_TILE - 1) / PT_TILE;

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import (BuildParams, BvhStats, Camera, Params, Sphere, MAT_DIFF, MAT_METAL, MAT_SPEC, MAT_REFR)
+from ._abi import (BuildParams, BvhStats, Camera, Material, Params, Sphere, MAT_DIFF, MAT_METAL, MAT_SPEC, MAT_REFR)
 
 ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets")
 
@@ -68,6 +68,44 @@ class Mesh:
     def tris(self):
         p = _abi.pthost().pth_mesh_tris(self._h)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), (self.n_tris, 3)).copy()
+
+    # per-triangle materials (extension; OBJ `usemtl` + .mtl, or PTMESH2 fixtures)
+    @property
+    def materials(self):
+        """List of Material rows ([] when the mesh carries none)."""
+        lib = _abi.pthost()
+        n = lib.pth_mesh_n_materials(self._h)
+        if n == 0:
+            return []
+        arr = C.cast(lib.pth_mesh_materials(self._h), C.POINTER(Material * n)).contents
+        out = []
+        for m in arr:
+            c = Material()
+            C.memmove(C.byref(c), C.byref(m), C.sizeof(Material))
+            out.append(c)
+        return out
+
+    @property
+    def tri_material(self):
+        """int32 material row per triangle (None when the mesh carries no materials)."""
+        p = _abi.pthost().pth_mesh_tri_materials(self._h)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), (self.n_tris,)).copy()
+
+    def set_materials(self, table, tri_material):
+        n = len(table) if table is not None else 0
+        arr = (Material * n)(*table) if n else None
+        ids = np.ascontiguousarray(tri_material, np.int32) if n else None
+        if n and len(ids) != self.n_tris:
+            raise ValueError("one material row per triangle expected")
+        if _abi.pthost().pth_mesh_set_materials(self._h, arr, n, ids.ctypes.data if n else None) != 0:
+            raise RuntimeError("pthost: " + _abi.pthost().pth_last_error().decode())
+        return self
+
+    def save(self, path):
+        if _abi.pthost().pth_mesh_save_ptmesh(self._h, path.encode()) != 0:
+            raise RuntimeError("pthost: " + _abi.pthost().pth_last_error().decode())
 
     def bounds(self):
         lo, hi = (C.c_float * 3)(), (C.c_float * 3)()
@@ -173,11 +211,24 @@ def scene_mesh(name):
     """Named benchmark meshes.
 
     cornell, dragon, gto_sixteen, bunny_low, cube, sphere : the committed fixtures
+    cornell_box         : CornellBox-Original with its 8 materials (PTMESH2; extension)
+    cornell_box_dragon  : cornell_box ∪ dragon as a gold Phong-metal object (100 036 tris)
     cornell_dragon      : cornell ∪ dragon (100 032 tris; both share one frame, F7)
     cornell_dragon_800k : cornell ∪ 8 dragon copies under fixed transforms inside the box
                           (800 032 tris) — deterministic stand-in for the missing
                           Assets/cornell_dragon.obj blob (.MISSING_LARGE_BLOBS:3)
     """
+    if name == "cornell_box_dragon":
+        # the material-carrying Cornell box (assets/cornell_box.ptmesh, lit by its own quad) with
+        # the dragon in it as a Phong-metal object: the per-triangle material extension's scene
+        m = Mesh.asset("cornell_box")
+        d = Mesh.asset("dragon")
+        gold = Material()
+        gold.col[:] = (0.9, 0.7, 0.3)
+        gold.emi[:] = (0.0, 0.0, 0.0)
+        gold.mat, gold.phong_expo = MAT_METAL, 30.0
+        d.set_materials([gold], np.zeros(d.n_tris, np.int32))
+        return m.append(d)
     if name == "cornell_dragon":
         m = Mesh.asset("cornell")
         return m.append(Mesh.asset("dragon"))

@@ -57,6 +57,8 @@ struct Node {
 struct pth_mesh {
     std::vector<float> verts;    // xyz
     std::vector<int32_t> tris;   // 3 per triangle
+    std::vector<pth_material> mats;   // empty: the file named no materials
+    std::vector<int32_t> tri_mat;     // row of `mats` per triangle (empty with mats)
 };
 
 struct pth_bvh {
@@ -458,31 +460,95 @@ pth_mesh* pth_mesh_load_ptmesh(const char* path) {
     FILE* f = std::fopen(path, "rb");
     if (!f) { set_err(std::string("cannot open ") + path); return nullptr; }
     char magic[8];
-    uint32_t nv = 0, nt = 0;
-    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTMESH1", 8) == 0 &&
-              std::fread(&nv, 4, 1, f) == 1 && std::fread(&nt, 4, 1, f) == 1;
+    uint32_t nv = 0, nt = 0, nm = 0;
+    bool ok = std::fread(magic, 1, 8, f) == 8;
+    const bool v2 = ok && std::memcmp(magic, "PTMESH2", 8) == 0;
+    ok = ok && (v2 || std::memcmp(magic, "PTMESH1", 8) == 0) &&
+         std::fread(&nv, 4, 1, f) == 1 && std::fread(&nt, 4, 1, f) == 1 && (!v2 || std::fread(&nm, 4, 1, f) == 1);
     std::vector<float> v;
-    std::vector<int32_t> t;
+    std::vector<int32_t> t, tm;
+    std::vector<pth_material> mats;
     if (ok) {
         v.resize(3 * (size_t)nv);
         t.resize(3 * (size_t)nt);
         ok = std::fread(v.data(), 4, v.size(), f) == v.size() && std::fread(t.data(), 4, t.size(), f) == t.size();
     }
+    if (ok && nm) {  // PTMESH2: material table + one row index per triangle
+        mats.resize(nm);
+        tm.resize(nt);
+        ok = std::fread(mats.data(), sizeof(pth_material), nm, f) == nm && std::fread(tm.data(), 4, nt, f) == nt;
+        for (size_t i = 0; ok && i < tm.size(); i++) ok = tm[i] >= 0 && (uint32_t)tm[i] < nm;
+    }
     std::fclose(f);
     if (!ok) { set_err(std::string("bad ptmesh file ") + path); return nullptr; }
-    return mesh_from(std::move(v), std::move(t));
+    pth_mesh* m = mesh_from(std::move(v), std::move(t));
+    if (m) { m->mats = std::move(mats); m->tri_mat = std::move(tm); }
+    return m;
 }
+
+namespace {
+// Wavefront .mtl → pth_material rows.  Kd → col, Ke → emi; the lobe follows `illum`:
+// 3 → METAL (Phong exponent Ns), 5 → SPEC (mirror), 4/6/7 → REFR (glass), anything else DIFF.
+// (The reference parses the .mtl through tinyobj and then ignores it: utilfun.cpp:458-462.)
+bool load_mtl(const std::string& path, std::vector<std::string>& names, std::vector<pth_material>& mats) {
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    std::vector<char> line(1 << 12);
+    std::vector<float> ns;
+    while (std::fgets(line.data(), (int)line.size(), f)) {
+        const char* s = line.data();
+        while (*s == ' ' || *s == '\t') s++;
+        char name[512];
+        float a, b, c;
+        int il;
+        if (std::sscanf(s, "newmtl %511s", name) == 1) {
+            names.emplace_back(name);
+            pth_material m{{0.8f, 0.8f, 0.8f}, {0.f, 0.f, 0.f}, 0, 0.f};
+            mats.push_back(m);
+            ns.push_back(0.f);
+        } else if (mats.empty()) {
+            continue;
+        } else if (std::sscanf(s, "Kd %f %f %f", &a, &b, &c) == 3) {
+            mats.back().col[0] = a; mats.back().col[1] = b; mats.back().col[2] = c;
+        } else if (std::sscanf(s, "Ke %f %f %f", &a, &b, &c) == 3) {
+            mats.back().emi[0] = a; mats.back().emi[1] = b; mats.back().emi[2] = c;
+        } else if (std::sscanf(s, "Ns %f", &a) == 1) {
+            ns.back() = a;
+        } else if (std::sscanf(s, "illum %d", &il) == 1) {
+            mats.back().mat = il == 3 ? 1 : il == 5 ? 2 : (il == 4 || il == 6 || il == 7) ? 3 : 0;
+        }
+    }
+    std::fclose(f);
+    for (size_t i = 0; i < mats.size(); i++) mats[i].phong_expo = mats[i].mat == 1 ? ns[i] : 0.f;
+    return true;
+}
+}  // namespace
+
 
 pth_mesh* pth_mesh_load_obj(const char* path) {
     FILE* f = std::fopen(path, "r");
     if (!f) { set_err(std::string("cannot open ") + path); return nullptr; }
     std::vector<float> v;
-    std::vector<int32_t> t;
+    std::vector<int32_t> t, tm;
+    std::vector<std::string> mat_names;
+    std::vector<pth_material> mats;
+    int32_t cur_mat = -1;      // -1: no usemtl seen yet
+    bool any_unnamed = false;
     std::vector<char> line(1 << 16);
     while (std::fgets(line.data(), (int)line.size(), f)) {
         const char* s = line.data();
         while (*s == ' ' || *s == '\t') s++;
-        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+        char word[1024];
+        if (s[0] == 'm' && std::sscanf(s, "mtllib %1023s", word) == 1) {
+            std::string dir(path);
+            const size_t slash = dir.find_last_of('/');
+            dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+            (void)load_mtl(dir + word, mat_names, mats);   // a missing .mtl leaves the mesh without materials
+        } else if (s[0] == 'u' && std::sscanf(s, "usemtl %1023s", word) == 1) {
+            cur_mat = -1;
+            for (size_t i = 0; i < mat_names.size(); i++)
+                if (mat_names[i] == word) cur_mat = (int32_t)i;
+        } else if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
             float x, y, z;
             if (std::sscanf(s + 1, "%f %f %f", &x, &y, &z) == 3) v.insert(v.end(), {x, y, z});
         } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
@@ -499,12 +565,25 @@ pth_mesh* pth_mesh_load_obj(const char* path) {
                 p = end;
                 while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') p++;  // skip /vt/vn
             }
-            for (size_t k = 1; k + 1 < poly.size(); k++) t.insert(t.end(), {poly[0], poly[k], poly[k + 1]});
+            for (size_t k = 1; k + 1 < poly.size(); k++) {
+                t.insert(t.end(), {poly[0], poly[k], poly[k + 1]});
+                tm.push_back(cur_mat);
+                any_unnamed = any_unnamed || cur_mat < 0;
+            }
         }
     }
     std::fclose(f);
     if (t.empty()) { set_err(std::string("no faces in ") + path); return nullptr; }
-    return mesh_from(std::move(v), std::move(t));
+    pth_mesh* m = mesh_from(std::move(v), std::move(t));
+    if (m && !mats.empty()) {
+        if (any_unnamed) {  // faces outside any usemtl get tinyobj's default grey
+            mats.push_back(pth_material{{0.8f, 0.8f, 0.8f}, {0.f, 0.f, 0.f}, 0, 0.f});
+            for (int32_t& i : tm) if (i < 0) i = (int32_t)mats.size() - 1;
+        }
+        m->mats = std::move(mats);
+        m->tri_mat = std::move(tm);
+    }
+    return m;
 }
 
 int pth_mesh_append(pth_mesh* dst, const pth_mesh* src, const float* m) {
@@ -524,7 +603,54 @@ int pth_mesh_append(pth_mesh* dst, const pth_mesh* src, const float* m) {
         }
         dst->verts.insert(dst->verts.end(), {x, y, z});
     }
+    // materials travel with the triangles; a side without a table gets one default grey row
+    const size_t nt_dst = dst->tris.size() / 3, nt_src = st.size() / 3;
+    if (!dst->mats.empty() || !src->mats.empty()) {
+        const std::vector<pth_material> sm(src->mats);
+        const std::vector<int32_t> stm(src->tri_mat);
+        const pth_material grey{{0.8f, 0.8f, 0.8f}, {0.f, 0.f, 0.f}, 0, 0.f};
+        if (dst->mats.empty()) { dst->mats.push_back(grey); dst->tri_mat.assign(nt_dst, 0); }
+        const int32_t mbase = (int32_t)dst->mats.size();
+        if (sm.empty()) {
+            dst->mats.push_back(grey);
+            dst->tri_mat.insert(dst->tri_mat.end(), nt_src, mbase);
+        } else {
+            dst->mats.insert(dst->mats.end(), sm.begin(), sm.end());
+            for (int32_t i : stm) dst->tri_mat.push_back(mbase + i);
+        }
+    }
     for (int32_t i : st) dst->tris.push_back(base + i);
+    return 0;
+}
+
+size_t pth_mesh_n_materials(const pth_mesh* m) { return m ? m->mats.size() : 0; }
+const pth_material* pth_mesh_materials(const pth_mesh* m) { return m && !m->mats.empty() ? m->mats.data() : nullptr; }
+const int32_t* pth_mesh_tri_materials(const pth_mesh* m) { return m && !m->mats.empty() ? m->tri_mat.data() : nullptr; }
+int pth_mesh_set_materials(pth_mesh* m, const pth_material* table, size_t n, const int32_t* tri_mat) {
+    if (!m) { set_err("null mesh"); return -1; }
+    if (n == 0) { m->mats.clear(); m->tri_mat.clear(); return 0; }
+    if (!table || !tri_mat) { set_err("null material arrays"); return -1; }
+    const size_t nt = m->tris.size() / 3;
+    for (size_t i = 0; i < nt; i++)
+        if (tri_mat[i] < 0 || (size_t)tri_mat[i] >= n) { set_err("material index out of range"); return -1; }
+    for (size_t i = 0; i < n; i++)
+        if (table[i].mat < 0 || table[i].mat > 3) { set_err("bad material type"); return -1; }
+    m->mats.assign(table, table + n);
+    m->tri_mat.assign(tri_mat, tri_mat + nt);
+    return 0;
+}
+int pth_mesh_save_ptmesh(const pth_mesh* m, const char* path) {
+    if (!m || !path) { set_err("null argument"); return -1; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { set_err(std::string("cannot write ") + path); return -1; }
+    const uint32_t nv = (uint32_t)(m->verts.size() / 3), nt = (uint32_t)(m->tris.size() / 3), nm = (uint32_t)m->mats.size();
+    bool ok = std::fwrite(nm ? "PTMESH2" : "PTMESH1", 1, 8, f) == 8 && std::fwrite(&nv, 4, 1, f) == 1 && std::fwrite(&nt, 4, 1, f) == 1;
+    if (nm) ok = ok && std::fwrite(&nm, 4, 1, f) == 1;
+    ok = ok && std::fwrite(m->verts.data(), 4, m->verts.size(), f) == m->verts.size() &&
+         std::fwrite(m->tris.data(), 4, m->tris.size(), f) == m->tris.size();
+    if (nm) ok = ok && std::fwrite(m->mats.data(), sizeof(pth_material), nm, f) == nm && std::fwrite(m->tri_mat.data(), 4, nt, f) == nt;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { set_err(std::string("write failed: ") + path); return -1; }
     return 0;
 }
 

@@ -56,10 +56,27 @@ typedef struct pth_bvh_stats {
 const char* pth_last_error(void);
 void pth_default_build_params(pth_build_params* p);
 
+/* One row of a per-triangle material table — same 32-byte layout as pt_material (include/ptmi.h),
+ * so the array goes to pt_upload_tri_materials as it is. */
+typedef struct pth_material {
+    float col[3];
+    float emi[3];
+    int32_t mat;         /* 0 DIFF, 1 METAL, 2 SPEC, 3 REFR (Mat, CommomStructs.hpp:16) */
+    float phong_expo;
+} pth_material;
+
 /* ---- meshes ---- */
 pth_mesh* pth_mesh_create(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris);
-pth_mesh* pth_mesh_load_obj(const char* path);      /* `v` / `f` records, fan-triangulated  */
+/* `v` / `f` records, polygons fan-triangulated, any number of o/g groups; `mtllib` + `usemtl`
+ * give every triangle a material row (Kd → col, Ke → emi, illum 3/5/4,6,7 → METAL/SPEC/REFR) */
+pth_mesh* pth_mesh_load_obj(const char* path);
 pth_mesh* pth_mesh_load_ptmesh(const char* path);   /* the committed .ptmesh fixtures under assets/ */
+int pth_mesh_save_ptmesh(const pth_mesh* m, const char* path);   /* PTMESH2 when the mesh has materials */
+/* per-triangle materials: n = 0 / NULL when the mesh has none */
+size_t pth_mesh_n_materials(const pth_mesh* m);
+const pth_material* pth_mesh_materials(const pth_mesh* m);
+const int32_t* pth_mesh_tri_materials(const pth_mesh* m);
+int pth_mesh_set_materials(pth_mesh* m, const pth_material* table, size_t n, const int32_t* tri_material);
 /* append src transformed by the row-major 3x4 affine m (NULL = identity) */
 int pth_mesh_append(pth_mesh* dst, const pth_mesh* src, const float* m3x4);
 size_t pth_mesh_n_verts(const pth_mesh* m);

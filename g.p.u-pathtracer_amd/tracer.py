@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import Camera, Counters, Params, Sphere
+from ._abi import Camera, Counters, Material, Params, Sphere
 
 
 class PtError(RuntimeError):
@@ -102,6 +102,16 @@ class PathTracer:
     def upload_spheres(self, spheres):
         n = len(spheres) if spheres is not None else 0
         self._check(self._lib.pt_upload_spheres(self._ctx, spheres if n else None, n))
+
+    def upload_tri_materials(self, table, tri_material):
+        """Per-triangle materials (extension): `table` = sequence of Material, `tri_material` =
+        int32 row per ORIGINAL triangle id.  table=None clears (one global material again)."""
+        if table is None or len(table) == 0:
+            self._check(self._lib.pt_upload_tri_materials(self._ctx, None, 0, None, 0))
+            return
+        arr = (Material * len(table))(*table)
+        ids = np.ascontiguousarray(tri_material, np.int32)
+        self._check(self._lib.pt_upload_tri_materials(self._ctx, arr, len(table), ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids)))
 
     def scene_info(self):
         a, b, c_, e = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

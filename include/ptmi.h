@@ -195,6 +195,22 @@ int pt_upload_bvh(pt_ctx* ctx,
                   const int32_t* tri_index, size_t n_index);
 int pt_upload_spheres(pt_ctx* ctx, const pt_sphere* spheres, size_t n_spheres);
 
+/* Per-triangle materials — an EXTENSION.  The reference parses the .mtl into
+ * `materials` but never reads it (utilfun.cpp:458-462) and shades every triangle with the ONE
+ * material of kernelInfo (tracer.cu:131-135 = pt_params.tri_mat/tri_col/tri_emi/phong_expo).
+ * After this call a triangle with ORIGINAL id i (the ids of the Compact index array) is shaded
+ * with table[tri_material[i]] instead; everything else of the path loop is unchanged.
+ * n_materials = 0 clears the table (back to the reference's behaviour).  n_tris must cover
+ * every id of the uploaded BVH.  Arrays are copied. */
+typedef struct pt_material {
+    float col[3];        /* albedo (mask *= col)                 */
+    float emi[3];        /* emitted radiance (accu += mask*emi)  */
+    int32_t mat;         /* PT_MAT_*                             */
+    float phong_expo;    /* METAL lobe exponent                  */
+} pt_material;           /* 32 bytes */
+int pt_upload_tri_materials(pt_ctx* ctx, const pt_material* table, size_t n_materials,
+                            const int32_t* tri_material, size_t n_tris);
+
 /* ---- the hot path -------------------------------------------------------------
  * render(accum, bvh, camera, spp) of BASELINE.json: fold `spp` consecutive samples
  * (frames params->frame .. frame+spp-1, running-mean N = sample_index .. +spp-1) into

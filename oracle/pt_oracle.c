@@ -388,7 +388,8 @@ void orc_camera_ray(const pt_camera* cam, int px, int py, int w, int h, float u0
 /* getSample, tracer.cu:27-339 */
 static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
                      const pt_sphere* sph, size_t n_sph, const pt_camera* cam,
-                     const pt_params* P, int px, int py, rng_t* rng, orc_counters* cnt) {
+                     const pt_params* P, const pt_material* mtab, const int32_t* tri_mat,
+                     int px, int py, rng_t* rng, orc_counters* cnt) {
     float o_[3], d_[3];
     float u0 = rng_next(rng), u1 = rng_next(rng);
     orc_camera_ray(cam, px, py, P->width, P->height, u0, u1, o_, d_);
@@ -413,6 +414,7 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
         v3 hitpos = vmadd(d, scene_t, o);
         v3 n, nl, objcol, emit;
         int mat;
+        float phong = P->phong_expo;
         if (geom == 1) {
             const pt_sphere* s = &sph[sph_id];
             n = vnormalize(vsub(hitpos, V(s->pos_rad[0], s->pos_rad[1], s->pos_rad[2])));
@@ -424,6 +426,13 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             n = vnormalize(h.n);
             nl = n; /* tracer.cu:126-127: the flip is a discarded expression */
             objcol = tricol; emit = triemi; mat = P->tri_mat;
+            if (mtab) { /* extension (ptmi.h pt_upload_tri_materials): per-triangle material row */
+                const pt_material* m = &mtab[tri_mat[h.tri]];
+                objcol = V(m->col[0], m->col[1], m->col[2]);
+                emit = V(m->emi[0], m->emi[1], m->emi[2]);
+                mat = m->mat;
+                phong = m->phong_expo;
+            }
         } else {
             return V(P->bk_color[0], P->bk_color[1], P->bk_color[2]); /* tracer.cu:140-142 */
         }
@@ -478,7 +487,7 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             float f1 = rng_next(rng), r2 = rng_next(rng);
             float cphi, sphi;
             orc_sincos2pi(f1, &cphi, &sphi);
-            float cosT = orc_pow01(1.0f - r2, 1.0f / (P->phong_expo + 1.0f));
+            float cosT = orc_pow01(1.0f - r2, 1.0f / (phong + 1.0f));
             float sinT = sqrtf(1.0f - cosT * cosT);
             v3 w1 = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
             v3 ax = ((double)fabsf(w1.x) > 0.1) ? V(0, 1, 0) : V(1, 0, 0);
@@ -525,6 +534,17 @@ int orc_render(float* accum, uint32_t* rgba,
                const float* nodes, const float* tris, const int32_t* tidx,
                const pt_sphere* sph, size_t n_sph,
                const pt_camera* cam, const pt_params* P, uint32_t spp, orc_counters* cnt) {
+    return orc_render_mat(accum, rgba, nodes, tris, tidx, sph, n_sph, NULL, NULL, cam, P, spp, cnt);
+}
+
+/* The same frame with per-triangle materials (the extension of ptmi.h's
+ * pt_upload_tri_materials): table row tri_mat[original triangle id]; mtab NULL = orc_render. */
+int orc_render_mat(float* accum, uint32_t* rgba,
+                   const float* nodes, const float* tris, const int32_t* tidx,
+                   const pt_sphere* sph, size_t n_sph,
+                   const pt_material* mtab, const int32_t* tri_mat,
+                   const pt_camera* cam, const pt_params* P, uint32_t spp, orc_counters* cnt) {
+    if (mtab && !tri_mat) return -1;
     if (!accum || !cam || !P || P->width <= 1 || P->height <= 1 || spp == 0) return -1;
     orc_counters total;
     memset(&total, 0, sizeof total);
@@ -542,7 +562,7 @@ int orc_render(float* accum, uint32_t* rgba,
                 uint64_t pix = (uint64_t)y * (uint64_t)W + (uint64_t)x;
                 for (uint32_t s = 0; s < spp; s++) {
                     rng_t rng = rng_init(P->frame + s, pix);
-                    v3 col = get_sample(nodes, tris, tidx, sph, n_sph, cam, P, x, y, &rng, &c);
+                    v3 col = get_sample(nodes, tris, tidx, sph, n_sph, cam, P, mtab, tri_mat, x, y, &rng, &c);
                     c.paths++;
                     float sm[3] = {col.x, col.y, col.z};
                     orc_accumulate(accum + 3 * pix, rgba ? rgba + pix : NULL, sm, P->sample_index + s);

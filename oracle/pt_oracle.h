@@ -31,6 +31,11 @@ int orc_render(float* accum, uint32_t* rgba,
                const float* nodes, const float* tris, const int32_t* tidx,
                const pt_sphere* sph, size_t n_sph,
                const pt_camera* cam, const pt_params* P, uint32_t spp, orc_counters* cnt);
+int orc_render_mat(float* accum, uint32_t* rgba,
+                   const float* nodes, const float* tris, const int32_t* tidx,
+                   const pt_sphere* sph, size_t n_sph,
+                   const pt_material* mtab, const int32_t* tri_mat,
+                   const pt_camera* cam, const pt_params* P, uint32_t spp, orc_counters* cnt);
 void orc_primary_rays(const pt_camera* cam, int W, int H, uint64_t frame, int jitter, float* rays8);
 
 #ifdef __cplusplus

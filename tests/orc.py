@@ -45,6 +45,9 @@ def lib():
         L.orc_render.restype = i32
         L.orc_render.argtypes = [vp, vp, vp, vp, vp, C.POINTER(g.Sphere), sz, C.POINTER(g.Camera),
                                  C.POINTER(g.Params), C.c_uint32, C.POINTER(g.Counters)]
+        L.orc_render_mat.restype = i32
+        L.orc_render_mat.argtypes = [vp, vp, vp, vp, vp, C.POINTER(g.Sphere), sz, C.POINTER(g.Material), vp,
+                                     C.POINTER(g.Camera), C.POINTER(g.Params), C.c_uint32, C.POINTER(g.Counters)]
         L.orc_primary_rays.restype = None
         L.orc_primary_rays.argtypes = [C.POINTER(g.Camera), i32, i32, C.c_uint64, i32, vp]
         _lib = L
@@ -55,8 +58,9 @@ def counters_dict(c):
     return {f: getattr(c, f) for f, _ in g.Counters._fields_}
 
 
-def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True):
-    """CPU restatement of trace<<<>>> (tracer.cu:343-400).  Returns accum, rgba, counters."""
+def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True, materials=None, tri_material=None):
+    """CPU restatement of trace<<<>>> (tracer.cu:343-400).  Returns accum, rgba, counters.
+    materials / tri_material: the per-triangle material extension (pt_upload_tri_materials)."""
     W, H = params.width, params.height
     if accum is None:
         accum = np.zeros((H, W, 3), np.float32)
@@ -66,8 +70,15 @@ def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True):
     nodes = bvh.nodes.ctypes.data if bvh is not None else None
     tris = bvh.tris.ctypes.data if bvh is not None else None
     idx = bvh.index.ctypes.data if bvh is not None else None
-    rc = lib().orc_render(accum.ctypes.data, rgba.ctypes.data if want_rgba else None, nodes, tris, idx,
-                          spheres if n_s else None, n_s, C.byref(cam), C.byref(params), spp, C.byref(cnt))
+    if materials is not None and len(materials):
+        mtab = (g.Material * len(materials))(*materials)
+        ids = np.ascontiguousarray(tri_material, np.int32)
+        rc = lib().orc_render_mat(accum.ctypes.data, rgba.ctypes.data if want_rgba else None, nodes, tris, idx,
+                                  spheres if n_s else None, n_s, mtab, ids.ctypes.data, C.byref(cam), C.byref(params),
+                                  spp, C.byref(cnt))
+    else:
+        rc = lib().orc_render(accum.ctypes.data, rgba.ctypes.data if want_rgba else None, nodes, tris, idx,
+                              spheres if n_s else None, n_s, C.byref(cam), C.byref(params), spp, C.byref(cnt))
     assert rc == 0
     return accum, rgba, counters_dict(cnt)
 

@@ -1,0 +1,212 @@
+"""Per-triangle materials — the extension of SURVEY.md §8 (f)1 (pt_upload_tri_materials).
+
+The reference shades every triangle with ONE global material and ignores the parsed .mtl
+(utilfun.cpp:458-462, tracer.cu:131-135), so it holds no fixture for this; the anchor is:
+a one-row table equal to the global material must reproduce the reference-faithful path bit
+for bit, and the GPU must equal the oracle's restatement of the extension bit for bit.
+CPU tests: .mtl / PTMESH2 ingest, the oracle.  GPU tests (-m gpu): parity through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import gpu_pathtracer_amd as g
+import orc
+
+
+def material(col, emi=(0, 0, 0), mat=g.MAT_DIFF, phong=0.0):
+    m = g.Material()
+    m.col[:] = col
+    m.emi[:] = emi
+    m.mat, m.phong_expo = mat, phong
+    return m
+
+
+def mixed_table():
+    return [material((0.75, 0.25, 0.25)), material((0.9, 0.7, 0.3), mat=g.MAT_METAL, phong=30.0),
+            material((0.95, 0.95, 0.95), mat=g.MAT_SPEC), material((1, 1, 1), mat=g.MAT_REFR),
+            material((0.78, 0.78, 0.78), emi=(17, 12, 4))]
+
+
+# ------------------------------------------------------------------------------ host ingest
+def test_cornell_box_fixture_carries_its_materials():
+    m = g.scene_mesh("cornell_box")
+    assert (m.n_tris, len(m.materials)) == (36, 8)
+    tm = m.tri_material
+    assert tm.shape == (36,) and tm.min() >= 0 and tm.max() == 7
+    light = [x for x in m.materials if max(x.emi) > 0]
+    assert len(light) == 1 and list(light[0].emi) == [17.0, 12.0, 4.0]
+    assert int((tm == 7).sum()) == 2           # the light quad = 2 triangles
+    reds = [x for x in m.materials if x.col[0] > 0.6 and x.col[1] < 0.1]
+    assert len(reds) == 1                      # leftWall
+
+
+def test_obj_mtl_parse_and_ptmesh2_round_trip(tmp_path):
+    (tmp_path / "t.mtl").write_text(
+        "newmtl a\nKd 0.1 0.2 0.3\nillum 2\n\nnewmtl glass\nKd 1 1 1\nNi 1.5\nillum 7\n"
+        "newmtl shiny\nKd 0.5 0.5 0.5\nNs 42\nillum 3\nnewmtl lamp\nKe 5 6 7\nnewmtl mirror\nillum 5\n")
+    (tmp_path / "t.obj").write_text(
+        "mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\n"
+        "f 1 2 3\nusemtl glass\nf 1 2 3 4\no second\nusemtl shiny\nf 1/1/1 2/2/2 5/3/3\nusemtl lamp\nf -1 -2 -3\n"
+        "usemtl nosuch\nf 1 3 5\nusemtl mirror\nf 2 3 5\n")
+    m = g.Mesh.load(str(tmp_path / "t.obj"))
+    assert m.n_tris == 7
+    mats, tm = m.materials, m.tri_material
+    assert len(mats) == 6                      # 5 named + the default grey for un-named faces
+    assert [mats[i].mat for i in range(5)] == [g.MAT_DIFF, g.MAT_REFR, g.MAT_METAL, g.MAT_DIFF, g.MAT_SPEC]
+    assert mats[2].phong_expo == 42.0 and list(mats[3].emi) == [5.0, 6.0, 7.0]
+    assert np.allclose(list(mats[0].col), [0.1, 0.2, 0.3])
+    assert tm.tolist() == [5, 1, 1, 2, 3, 5, 4]  # face before usemtl / unknown name -> default row
+    m.save(str(tmp_path / "t.ptmesh"))
+    r = g.Mesh.load(str(tmp_path / "t.ptmesh"))
+    assert np.array_equal(r.verts, m.verts) and np.array_equal(r.tris, m.tris)
+    assert np.array_equal(r.tri_material, tm)
+    assert [bytes(a) for a in r.materials] == [bytes(a) for a in mats]
+    # a mesh without materials still writes / reads PTMESH1
+    p = g.Mesh.from_arrays(m.verts, m.tris)
+    p.save(str(tmp_path / "p.ptmesh"))
+    assert open(tmp_path / "p.ptmesh", "rb").read(8) == b"PTMESH1\0"
+    assert g.Mesh.load(str(tmp_path / "p.ptmesh")).tri_material is None
+
+
+def test_append_merges_material_tables():
+    box = g.scene_mesh("cornell_box")
+    cube = g.Mesh.asset("cube")               # no materials: gets one default grey row
+    n0 = len(box.materials)
+    box.append(cube)
+    assert len(box.materials) == n0 + 1 and box.n_tris == 36 + 12
+    assert (box.tri_material[36:] == n0).all()
+    both = g.scene_mesh("cornell_box_dragon")
+    assert both.n_tris == 100036 and both.materials[-1].mat == g.MAT_METAL
+    with pytest.raises((RuntimeError, ValueError)):
+        cube.set_materials([material((1, 1, 1))], np.full(12, 3, np.int32))   # row out of range
+
+
+# ------------------------------------------------------------------------------ oracle
+def test_oracle_one_row_table_equals_the_global_material():
+    mesh = g.scene_mesh("cornell")
+    bvh = g.Bvh(mesh)
+    W, H = 96, 64
+    cam, p = g.default_camera(W, H), g.default_params(W, H, tri_mat=g.MAT_METAL)
+    one = material(list(p.tri_col), list(p.tri_emi), p.tri_mat, p.phong_expo)
+    a, ra, _ = orc.render(bvh, g.reference_spheres(), cam, p, 3)
+    b, rb, _ = orc.render(bvh, g.reference_spheres(), cam, p, 3, materials=[one], tri_material=np.zeros(mesh.n_tris, np.int32))
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
+def test_oracle_light_quad_lights_the_box():
+    mesh = g.scene_mesh("cornell_box")
+    bvh = g.Bvh(mesh)
+    W, H = 160, 120                            # default camera: dist = H / 60 (integer divide)
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.bk_color[:] = (0, 0, 0)
+    dark, _, _ = orc.render(bvh, None, cam, p, 8)                      # global material: no emitter anywhere
+    lit, _, _ = orc.render(bvh, None, cam, p, 8, materials=mesh.materials, tri_material=mesh.tri_material)
+    assert dark.max() == 0.0
+    assert lit.max() == 1.0 and lit.mean() > 0.01
+    red, green = lit[:, : W // 5].mean(axis=(0, 1)), lit[:, -W // 5:].mean(axis=(0, 1))
+    assert red[0] > 2 * red[1] and green[1] > 1.25 * green[0]         # leftWall red, rightWall green (under an orange light)
+
+
+# ------------------------------------------------------------------------------ GPU parity
+GPU_VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "persistent-wide": (g.KERNEL_PERSISTENT, 2),
+                "mega-unified": (g.KERNEL_MEGA_BVH2, 1), "persistent-whilewhile": (g.KERNEL_PERSISTENT, 0)}
+
+
+@pytest.fixture(scope="module", params=list(GPU_VARIANTS), ids=list(GPU_VARIANTS))
+def pt(request):
+    t = g.PathTracer(0)
+    t.set_option(g.OPT_KERNEL, GPU_VARIANTS[request.param][0])
+    t.set_option(g.OPT_WALK, GPU_VARIANTS[request.param][1])
+    # walks 0/1 share the oracle's slab arithmetic: bit-exact; the wide walks' quantised boxes may let
+    # a grazing candidate through that the binary tree culls (test_gpu_wide.py): <= 2 pixels
+    t.max_diff = 2 if GPU_VARIANTS[request.param][1] >= 2 else 0
+    yield t
+    t.close()
+
+
+def _gpu(pt, bvh, sph, cam, p, spp, table, ids):
+    pt.upload_tri_materials(None, None)
+    pt.upload_bvh(bvh)
+    pt.upload_spheres(sph)
+    pt.upload_tri_materials(table, ids)
+    acc, rgba = pt.alloc_frame(p.width, p.height)
+    pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+    pt.sync()
+    a = acc.download(np.float32, (p.height, p.width, 3))
+    r = rgba.download(np.uint32, (p.height, p.width))
+    acc.free()
+    rgba.free()
+    return a, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,spheres,W,H,spp", [("cornell_box", False, 320, 240, 4), ("cornell_box_dragon", False, 640, 360, 2),
+                                                  ("cornell_box_dragon", True, 257, 131, 3)])
+def test_gpu_equals_oracle_with_file_materials(pt, scene, spheres, W, H, spp):
+    mesh = g.scene_mesh(scene)
+    bvh = g.Bvh(mesh)
+    sph = g.reference_spheres() if spheres else None
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.depth, p.frame, p.flags = 6, 11, g.FLAG_WRITE_RGBA
+    p.bk_color[:] = (0, 0, 0)
+    ref, rref, _ = orc.render(bvh, sph, cam, p, spp, materials=mesh.materials, tri_material=mesh.tri_material)
+    a, r = _gpu(pt, bvh, sph, cam, p, spp, mesh.materials, mesh.tri_material)
+    n_diff = int(np.any(a != ref, axis=-1).sum())
+    print(f"{scene}: differing pixels {n_diff} of {W * H}; mean {a.mean():.4f}")
+    assert n_diff <= pt.max_diff
+    if n_diff == 0:
+        assert np.array_equal(r, rref)
+    assert a.mean() > 0.005
+
+
+@pytest.mark.gpu
+def test_gpu_all_lobes_per_triangle(pt):
+    """Every triangle of the dragon scene gets one of five rows (DIFF / METAL / SPEC / REFR / emitter)."""
+    mesh = g.scene_mesh("cornell_dragon")
+    bvh = g.Bvh(mesh)
+    table = mixed_table()
+    ids = (np.arange(mesh.n_tris) * 7919 % 1009 % len(table)).astype(np.int32)
+    ids[:32] = 0                                # the box itself diffuse
+    W, H = 480, 270
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.depth, p.frame = 5, 3
+    sph = g.reference_spheres()
+    ref, _, _ = orc.render(bvh, sph, cam, p, 2, materials=table, tri_material=ids)
+    a, _ = _gpu(pt, bvh, sph, cam, p, 2, table, ids)
+    assert int(np.any(a != ref, axis=-1).sum()) <= pt.max_diff
+    glob, _, _ = orc.render(bvh, sph, cam, p, 2)
+    assert np.any(ref != glob)                  # the table really changes the picture
+
+
+@pytest.mark.gpu
+def test_gpu_one_row_table_and_clear_equal_global(pt):
+    mesh = g.scene_mesh("cornell_dragon")
+    bvh = g.Bvh(mesh)
+    W, H = 320, 180
+    cam, p = g.default_camera(W, H), g.default_params(W, H, tri_mat=g.MAT_SPEC)
+    sph = g.reference_spheres()
+    one = material(list(p.tri_col), list(p.tri_emi), p.tri_mat, p.phong_expo)
+    a_tab, _ = _gpu(pt, bvh, sph, cam, p, 2, [one], np.zeros(mesh.n_tris, np.int32))
+    a_glob, _ = _gpu(pt, bvh, sph, cam, p, 2, None, None)
+    assert np.array_equal(a_tab, a_glob)
+
+
+@pytest.mark.gpu
+def test_gpu_material_upload_errors(pt):
+    mesh = g.scene_mesh("cornell")
+    pt.upload_tri_materials(None, None)
+    pt.upload_bvh(g.Bvh(mesh))
+    good = [material((1, 1, 1))]
+    with pytest.raises(g.PtError):
+        pt.upload_tri_materials(good, np.zeros(mesh.n_tris - 1, np.int32))      # does not cover the BVH's ids
+    with pytest.raises(g.PtError):
+        pt.upload_tri_materials(good, np.ones(mesh.n_tris, np.int32))           # row out of range
+    bad = [material((1, 1, 1), mat=9)]
+    with pytest.raises(g.PtError):
+        pt.upload_tri_materials(bad, np.zeros(mesh.n_tris, np.int32))
+    pt.upload_tri_materials(good, np.zeros(mesh.n_tris, np.int32))
+    with pytest.raises(g.PtError):
+        pt.upload_bvh(g.Bvh(g.scene_mesh("bunny_low")))                         # more triangles than the table covers
+    pt.upload_tri_materials(None, None)
+    pt.upload_bvh(g.Bvh(g.scene_mesh("bunny_low")))

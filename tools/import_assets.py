@@ -14,6 +14,8 @@ GpuPathTracer/utilfun.cpp:393-530).  This script is only runnable where
     u32   n_verts, n_tris
     f32   verts[n_verts][3]
     i32   tris[n_tris][3]          (0-based vertex indices)
+"PTMESH2\0" adds u32 n_materials after n_tris and, after tris, the material rows
+(32 bytes each: col[3], emi[3], i32 mat, f32 phong) and i32 tri_material[n_tris].
 """
 import os
 import struct
@@ -51,8 +53,28 @@ def write_ptmesh(path, verts, tris):
         f.write(tris.astype("<i4").tobytes())
 
 
+def import_cornell_box():
+    """cornellBox/CornellBox/CornellBox-Original.obj + .mtl (McGuire's public-domain data set, 36
+    triangles, 8 materials, one emissive quad) -> assets/cornell_box.ptmesh (PTMESH2: + material
+    table + one row per triangle), moved into the frame cornell.obj lives in so that the
+    reference's default camera sees it: p' = 15.5 * (p - (0, 1, 1)) + (0, 0, -28)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import gpu_pathtracer_amd as g
+    src = os.path.join(REF, "cornellBox", "CornellBox", "CornellBox-Original.obj")
+    if not os.path.exists(src):
+        print("missing", src, file=sys.stderr)
+        return
+    m = g.Mesh.load(src)
+    v = (m.verts.astype(np.float32) - np.array([0, 1, 1], np.float32)) * np.float32(15.5) + np.array([0, 0, -28], np.float32)
+    out = g.Mesh.from_arrays(v, m.tris).set_materials(m.materials, m.tri_material)
+    dst = os.path.join(OUT, "cornell_box.ptmesh")
+    out.save(dst)
+    print(f"cornell_box: {out.n_verts} verts {out.n_tris} tris {len(out.materials)} materials -> {os.path.getsize(dst)} B")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    import_cornell_box()
     for name in MESHES:
         src = os.path.join(REF, name + ".obj")
         if not os.path.exists(src):
