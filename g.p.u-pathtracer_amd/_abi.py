@@ -34,6 +34,12 @@ class Material(C.Structure):
     _fields_ = [("col", C.c_float * 3), ("emi", C.c_float * 3), ("mat", C.c_int32), ("phong_expo", C.c_float)]
 
 
+class CheckpointInfo(C.Structure):
+    """pth_checkpoint_info (host/pthost.h)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("next_frame", C.c_uint64),
+                ("constant_pdf", C.c_uint64), ("scene_tag", C.c_uint64)]
+
+
 class Params(C.Structure):
     """pt_params — scalar part of kernelInfo, GpuPathTracer/CpuStructs.hpp:45-72."""
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_uint32),
@@ -123,6 +129,11 @@ PTHOST_SYMBOLS = [
     ("pth_bvh_n_index", _sz, [_vp]),
     ("pth_bvh_get_stats", None, [_vp, C.POINTER(BvhStats)]),
     ("pth_bvh_free", None, [_vp]),
+    ("pth_write_ppm", _i, [C.c_char_p, _vp, _i, _i]),
+    ("pth_write_png", _i, [C.c_char_p, _vp, _i, _i]),
+    ("pth_write_pfm", _i, [C.c_char_p, _vp, _i, _i]),
+    ("pth_checkpoint_save", _i, [C.c_char_p, C.POINTER(CheckpointInfo), _vp]),
+    ("pth_checkpoint_load", _i, [C.c_char_p, C.POINTER(CheckpointInfo), _vp]),
     ("pth_frame_hash", C.c_uint64, [C.c_uint64]),
 ]
 

@@ -148,6 +148,40 @@ class Bvh:
         lib.pth_bvh_free(h)
 
 
+def _host_call(rc):
+    if rc != 0:
+        raise RuntimeError("pthost: " + _abi.pthost().pth_last_error().decode())
+
+
+def write_image(path, frame):
+    """.ppm / .png from the display words (uint32 [H][W], 0x00BBGGRR), .pfm from the float
+    accumulator ([H][W][3]); rows are bottom-up in both buffers, as the kernel stores them."""
+    lib = _abi.pthost()
+    if path.endswith(".pfm"):
+        a = np.ascontiguousarray(frame, np.float32)
+        _host_call(lib.pth_write_pfm(path.encode(), a.ctypes.data, a.shape[1], a.shape[0]))
+    else:
+        a = np.ascontiguousarray(frame, np.uint32)
+        fn = lib.pth_write_png if path.endswith(".png") else lib.pth_write_ppm
+        _host_call(fn(path.encode(), a.ctypes.data, a.shape[1], a.shape[0]))
+
+
+def save_checkpoint(path, accum, next_frame, constant_pdf, scene_tag=0):
+    a = np.ascontiguousarray(accum, np.float32)
+    ci = _abi.CheckpointInfo(a.shape[1], a.shape[0], next_frame, constant_pdf, scene_tag)
+    _host_call(_abi.pthost().pth_checkpoint_save(path.encode(), C.byref(ci), a.ctypes.data))
+
+
+def load_checkpoint(path):
+    """-> (accum [H][W][3] float32, next_frame, constant_pdf, scene_tag)"""
+    lib = _abi.pthost()
+    ci = _abi.CheckpointInfo()
+    _host_call(lib.pth_checkpoint_load(path.encode(), C.byref(ci), None))
+    a = np.empty((ci.height, ci.width, 3), np.float32)
+    _host_call(lib.pth_checkpoint_load(path.encode(), C.byref(ci), a.ctypes.data))
+    return a, ci.next_frame, ci.constant_pdf, ci.scene_tag
+
+
 def frame_hash(frame):
     """uf::hash(frameNumber), GpuPathTracer/utilfun.cpp:380-389."""
     return _abi.pthost().pth_frame_hash(frame)

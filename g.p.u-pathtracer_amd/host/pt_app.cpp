@@ -4,8 +4,15 @@
 //   per frame:  sync (BasicScene.cpp:395) → frame seed (:397) → constantPdf logic (:399)
 //               → launchKernel (:404) → [display copy :424-432 → here: optional download]
 //
-// Usage: pt_app --mesh assets/cornell.ptmesh [--width 1280 --height 720 --frames 16
-//               --depth 4 --mat 0..3 --no-spheres --device 0 --out image.ppm]
+// Usage: pt_app --mesh assets/cornell.ptmesh [--width 1280 --height 720 --frames 16 --spp 1
+//               --depth 4 --mat 0..3 --no-spheres --no-materials --bk r g b --device 0
+//               --out image.ppm|.png|.pfm  --checkpoint state.ckpt [--checkpoint-every N]
+//               --resume state.ckpt]
+// --frames counts samples per pixel in total; --spp of them are folded per pt_render call.
+// A mesh that carries materials (OBJ usemtl + .mtl, PTMESH2) is shaded with them
+// (pt_upload_tri_materials) unless --no-materials.  --resume continues a checkpointed
+// progressive render: the result is bit-identical to one uninterrupted run.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,9 +29,10 @@ static int die(const char* what, const char* msg) {
 }
 
 int main(int argc, char** argv) {
-    std::string mesh_path, out_path;
-    int W = 1280, H = 720, frames = 16, depth = 4, mat = PT_MAT_DIFF, device = 0;
-    bool spheres = true;
+    std::string mesh_path, out_path, ckpt_path, resume_path;
+    int W = 1280, H = 720, frames = 16, depth = 4, mat = PT_MAT_DIFF, device = 0, spp = 1, ckpt_every = 0;
+    bool spheres = true, use_materials = true;
+    float bk[3] = {1.f, 1.f, 1.f};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&](const char* name) -> const char* {
@@ -40,9 +48,16 @@ int main(int argc, char** argv) {
         else if (a == "--mat") mat = std::atoi(next("--mat"));
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--no-spheres") spheres = false;
+        else if (a == "--no-materials") use_materials = false;
+        else if (a == "--spp") spp = std::atoi(next("--spp"));
+        else if (a == "--checkpoint") ckpt_path = next("--checkpoint");
+        else if (a == "--checkpoint-every") ckpt_every = std::atoi(next("--checkpoint-every"));
+        else if (a == "--resume") resume_path = next("--resume");
+        else if (a == "--bk") { for (int k = 0; k < 3; k++) bk[k] = (float)std::atof(next("--bk")); }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (mesh_path.empty()) return die("usage", "--mesh <file.obj|file.ptmesh> is required");
+    if (spp < 1 || frames < 0 || W < 2 || H < 2) return die("usage", "--spp >= 1, --frames >= 0, --width/--height >= 2");
 
     const bool is_ptmesh = mesh_path.size() > 7 && mesh_path.substr(mesh_path.size() - 7) == ".ptmesh";
     pth_mesh* mesh = is_ptmesh ? pth_mesh_load_ptmesh(mesh_path.c_str()) : pth_mesh_load_obj(mesh_path.c_str());
@@ -59,6 +74,14 @@ int main(int argc, char** argv) {
     if (pt_upload_bvh(ctx, pth_bvh_nodes(bvh), pth_bvh_n_node_vec4(bvh), pth_bvh_tris(bvh), pth_bvh_n_tri_vec4(bvh),
                       pth_bvh_index(bvh), pth_bvh_n_index(bvh)) != PT_OK)
         return die("pt_upload_bvh", pt_last_error(ctx));
+    const bool has_materials = use_materials && pth_mesh_n_materials(mesh) > 0;
+    if (has_materials) {
+        static_assert(sizeof(pth_material) == sizeof(pt_material), "one layout");
+        if (pt_upload_tri_materials(ctx, (const pt_material*)pth_mesh_materials(mesh), pth_mesh_n_materials(mesh),
+                                    pth_mesh_tri_materials(mesh), pth_mesh_n_tris(mesh)) != PT_OK)
+            return die("pt_upload_tri_materials", pt_last_error(ctx));
+        std::printf("%zu materials from the mesh file\n", pth_mesh_n_materials(mesh));
+    }
 
     // the reference's sphere room, BasicScene.cpp:181-202
     std::vector<pt_sphere> sph;
@@ -92,7 +115,7 @@ int main(int argc, char** argv) {
     p.width = W; p.height = H; p.depth = (uint32_t)depth; p.cull_backfaces = 1;
     p.tri_mat = mat;
     p.tri_col[0] = 246.f / 256.f; p.tri_col[1] = 246.f / 255.f; p.tri_col[2] = 70.f / 255.f;
-    p.bk_color[0] = p.bk_color[1] = p.bk_color[2] = 1.f;
+    p.bk_color[0] = bk[0]; p.bk_color[1] = bk[1]; p.bk_color[2] = bk[2];
     p.air_ior = 1.0f; p.glass_ior = 1.4f; p.phong_expo = 30.f;
     p.flags = PT_FLAG_WRITE_RGBA;
     p.part_count = 1; p.part_rows = 8;
@@ -102,37 +125,77 @@ int main(int argc, char** argv) {
         return die("pt_malloc", pt_last_error(ctx));
     pt_memset(ctx, accum, 0, (size_t)W * H * 12);
 
-    uint64_t constantPdf = 0;
-    bool cam_dirty = true;  // first frame overwrites (BasicScene.cpp:399)
+    // what a checkpoint must agree on to be continued: geometry size, image size, the scalar parameters
+    uint64_t tag = pth_frame_hash((uint64_t)pth_mesh_n_tris(mesh) * 1315423911ull + (uint64_t)W * 65537u + (uint64_t)H);
+    tag = pth_frame_hash(tag ^ ((uint64_t)depth << 32 | (uint64_t)mat << 8 | (spheres ? 2u : 0u) | (has_materials ? 1u : 0u)));
+
+    uint64_t frameNumber = 0, constantPdf = 0;   // constantPdf = samples folded so far
+    std::vector<float> host_acc;
+    if (!resume_path.empty()) {
+        pth_checkpoint_info ci{};
+        host_acc.resize((size_t)W * H * 3);
+        if (pth_checkpoint_load(resume_path.c_str(), &ci, nullptr) != 0) return die("resume", pth_last_error());
+        if (ci.width != W || ci.height != H || ci.scene_tag != tag) return die("resume", "checkpoint belongs to another scene / image size / parameters");
+        if (pth_checkpoint_load(resume_path.c_str(), &ci, host_acc.data()) != 0) return die("resume", pth_last_error());
+        if (pt_upload(ctx, accum, host_acc.data(), host_acc.size() * 4) != PT_OK) return die("pt_upload", pt_last_error(ctx));
+        frameNumber = ci.next_frame;
+        constantPdf = ci.constant_pdf;
+        std::printf("resumed %s: %llu samples per pixel done\n", resume_path.c_str(), (unsigned long long)constantPdf);
+    }
+    auto save_checkpoint = [&]() -> int {
+        host_acc.resize((size_t)W * H * 3);
+        if (pt_download(ctx, host_acc.data(), accum, host_acc.size() * 4) != PT_OK) return die("pt_download", pt_last_error(ctx));
+        pth_checkpoint_info ci{W, H, frameNumber, constantPdf, tag};
+        if (pth_checkpoint_save(ckpt_path.c_str(), &ci, host_acc.data()) != 0) return die("checkpoint", pth_last_error());
+        return 0;
+    };
+
+    const uint64_t end_frame = frameNumber + (uint64_t)frames;
+    int calls = 0;
     auto t0 = std::chrono::steady_clock::now();
-    for (uint64_t frameNumber = 0; frameNumber < (uint64_t)frames; ++frameNumber) {
+    while (frameNumber < end_frame) {
         if (pt_sync(ctx) != PT_OK) return die("pt_sync", pt_last_error(ctx));       // :395
+        const uint32_t n = (uint32_t)std::min<uint64_t>((uint64_t)spp, end_frame - frameNumber);
         p.frame = frameNumber;                                                      // :397
-        constantPdf = cam_dirty ? 1 : constantPdf + 1;                              // :399
-        cam_dirty = false;
-        p.sample_index = constantPdf;
-        if (pt_render(ctx, (float*)accum, (uint32_t*)rgba, &cam, &p, 1) != PT_OK)   // :404
+        p.sample_index = constantPdf + 1;                                           // :399 (1 on the first frame: overwrite)
+        if (pt_render(ctx, (float*)accum, (uint32_t*)rgba, &cam, &p, n) != PT_OK)   // :404
             return die("pt_render", pt_last_error(ctx));
+        frameNumber += n;
+        constantPdf += n;
+        calls++;
+        if (!ckpt_path.empty() && ckpt_every > 0 && calls % ckpt_every == 0 && frameNumber < end_frame)
+            if (int rc = save_checkpoint()) return rc;
     }
     pt_sync(ctx);
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const double rays = (double)W * H * depth * frames;
-    std::printf("%d frames %dx%d depth %d: %.2f ms/frame, <= %.1f Mrays/s (closed scene bound)\n", frames, W, H, depth,
-                ms / frames, rays / ms / 1e3);
+    std::printf("%d samples/pixel %dx%d depth %d in %d calls: %.2f ms/sample, <= %.1f Mrays/s (closed scene bound)\n", frames, W, H,
+                depth, calls, frames ? ms / frames : 0.0, ms > 0 ? rays / ms / 1e3 : 0.0);
+    if (!ckpt_path.empty())
+        if (int rc = save_checkpoint()) return rc;
 
     if (!out_path.empty()) {
-        std::vector<uint32_t> img((size_t)W * H);
-        if (pt_download(ctx, img.data(), rgba, img.size() * 4) != PT_OK) return die("pt_download", pt_last_error(ctx));
-        FILE* f = std::fopen(out_path.c_str(), "wb");
-        if (!f) return die("open", out_path.c_str());
-        std::fprintf(f, "P6\n%d %d\n255\n", W, H);
-        for (int y = H - 1; y >= 0; y--)
-            for (int x = 0; x < W; x++) {
-                uint32_t w = img[(size_t)y * W + x];
-                unsigned char rgb[3] = {(unsigned char)(w & 255), (unsigned char)((w >> 8) & 255), (unsigned char)((w >> 16) & 255)};
-                std::fwrite(rgb, 1, 3, f);
+        const std::string ext = out_path.size() > 4 ? out_path.substr(out_path.size() - 4) : std::string();
+        int rc;
+        if (ext == ".pfm") {
+            host_acc.resize((size_t)W * H * 3);
+            if (pt_download(ctx, host_acc.data(), accum, host_acc.size() * 4) != PT_OK) return die("pt_download", pt_last_error(ctx));
+            rc = pth_write_pfm(out_path.c_str(), host_acc.data(), W, H);
+        } else {
+            std::vector<uint32_t> img((size_t)W * H);
+            if (frames == 0) {  // nothing rendered in this run (e.g. --resume only to convert): pack the accumulator here
+                host_acc.resize((size_t)W * H * 3);
+                if (pt_download(ctx, host_acc.data(), accum, host_acc.size() * 4) != PT_OK) return die("pt_download", pt_last_error(ctx));
+                for (size_t i = 0; i < img.size(); i++) {   // rgbToUint, cudaUtils.h:99-105
+                    auto q = [&](float v) { v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); return (uint32_t)(v * 255.f); };
+                    img[i] = q(host_acc[3 * i]) | (q(host_acc[3 * i + 1]) << 8) | (q(host_acc[3 * i + 2]) << 16);
+                }
+            } else if (pt_download(ctx, img.data(), rgba, img.size() * 4) != PT_OK) {
+                return die("pt_download", pt_last_error(ctx));
             }
-        std::fclose(f);
+            rc = ext == ".png" ? pth_write_png(out_path.c_str(), img.data(), W, H) : pth_write_ppm(out_path.c_str(), img.data(), W, H);
+        }
+        if (rc != 0) return die("write", pth_last_error());
     }
     pt_free(ctx, accum);
     pt_free(ctx, rgba);

@@ -725,6 +725,131 @@ size_t pth_bvh_n_index(const pth_bvh* b) { return b->index.size(); }
 void pth_bvh_get_stats(const pth_bvh* b, pth_bvh_stats* out) { *out = b->stats; }
 void pth_bvh_free(pth_bvh* b) { delete b; }
 
+// ---- image output -----------------------------------------------------------------------
+static void rgb_row(const uint32_t* row, int W, std::vector<unsigned char>& out) {
+    for (int x = 0; x < W; x++) {
+        const uint32_t w = row[x];
+        out.push_back((unsigned char)(w & 255)); out.push_back((unsigned char)((w >> 8) & 255)); out.push_back((unsigned char)((w >> 16) & 255));
+    }
+}
+
+int pth_write_ppm(const char* path, const uint32_t* rgba, int W, int H) {
+    if (!path || !rgba || W <= 0 || H <= 0) { set_err("pth_write_ppm: bad argument"); return -1; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { set_err(std::string("cannot write ") + path); return -1; }
+    std::fprintf(f, "P6\n%d %d\n255\n", W, H);
+    std::vector<unsigned char> row;
+    bool ok = true;
+    for (int y = H - 1; y >= 0 && ok; y--) {
+        row.clear();
+        rgb_row(rgba + (size_t)y * W, W, row);
+        ok = std::fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { set_err(std::string("write failed: ") + path); return -1; }
+    return 0;
+}
+
+static uint32_t crc32_of(const unsigned char* p, size_t n, uint32_t crc = 0) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    return ~crc;
+}
+static void be32(std::vector<unsigned char>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((unsigned char)(x >> s)); }
+static bool png_chunk(FILE* f, const char* type, const std::vector<unsigned char>& data) {
+    std::vector<unsigned char> buf;
+    be32(buf, (uint32_t)data.size());
+    buf.insert(buf.end(), type, type + 4);
+    buf.insert(buf.end(), data.begin(), data.end());
+    const uint32_t crc = crc32_of(buf.data() + 4, buf.size() - 4);
+    be32(buf, crc);
+    return std::fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+}
+
+int pth_write_png(const char* path, const uint32_t* rgba, int W, int H) {
+    if (!path || !rgba || W <= 0 || H <= 0) { set_err("pth_write_png: bad argument"); return -1; }
+    // raw scanlines (filter byte 0 + RGB), top row first
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)H * (3 * (size_t)W + 1));
+    for (int y = H - 1; y >= 0; y--) { raw.push_back(0); rgb_row(rgba + (size_t)y * W, W, raw); }
+    // zlib stream of stored deflate blocks (<= 65535 bytes each) + adler32
+    std::vector<unsigned char> z{0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 255)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 255)); z.push_back((unsigned char)((~n >> 8) & 255));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        for (size_t i = off; i < off + n; i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        off += n;
+    }
+    be32(z, (b << 16) | a);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { set_err(std::string("cannot write ") + path); return -1; }
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<unsigned char> hdr;
+    be32(hdr, (uint32_t)W); be32(hdr, (uint32_t)H);
+    hdr.insert(hdr.end(), {8, 2, 0, 0, 0});  // 8 bit, truecolour
+    bool ok = std::fwrite(sig, 1, 8, f) == 8 && png_chunk(f, "IHDR", hdr) && png_chunk(f, "IDAT", z) && png_chunk(f, "IEND", {});
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { set_err(std::string("write failed: ") + path); return -1; }
+    return 0;
+}
+
+int pth_write_pfm(const char* path, const float* accum, int W, int H) {
+    if (!path || !accum || W <= 0 || H <= 0) { set_err("pth_write_pfm: bad argument"); return -1; }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { set_err(std::string("cannot write ") + path); return -1; }
+    std::fprintf(f, "PF\n%d %d\n-1.0\n", W, H);   // negative scale = little endian; rows bottom-up, as stored
+    const size_t n = (size_t)W * H * 3;
+    bool ok = std::fwrite(accum, 4, n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { set_err(std::string("write failed: ") + path); return -1; }
+    return 0;
+}
+
+int pth_checkpoint_save(const char* path, const pth_checkpoint_info* info, const float* accum) {
+    if (!path || !info || !accum || info->width <= 0 || info->height <= 0) { set_err("pth_checkpoint_save: bad argument"); return -1; }
+    const std::string tmp = std::string(path) + ".tmp";   // write-then-rename: a killed run never leaves half a file
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) { set_err(std::string("cannot write ") + tmp); return -1; }
+    const size_t n = (size_t)info->width * info->height * 3;
+    const uint32_t crc = crc32_of((const unsigned char*)accum, n * 4);
+    bool ok = std::fwrite("PTCKPT1", 1, 8, f) == 8 && std::fwrite(info, sizeof *info, 1, f) == 1 && std::fwrite(&crc, 4, 1, f) == 1 &&
+              std::fwrite(accum, 4, n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path) != 0) { set_err(std::string("write failed: ") + path); return -1; }
+    return 0;
+}
+
+int pth_checkpoint_load(const char* path, pth_checkpoint_info* info, float* accum) {
+    if (!path || !info) { set_err("pth_checkpoint_load: bad argument"); return -1; }
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { set_err(std::string("cannot open ") + path); return -1; }
+    char magic[8];
+    uint32_t crc = 0;
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "PTCKPT1", 8) == 0 && std::fread(info, sizeof *info, 1, f) == 1 &&
+              std::fread(&crc, 4, 1, f) == 1 && info->width > 0 && info->height > 0;
+    if (ok && accum) {
+        const size_t n = (size_t)info->width * info->height * 3;
+        ok = std::fread(accum, 4, n, f) == n && crc32_of((const unsigned char*)accum, n * 4) == crc;
+    }
+    std::fclose(f);
+    if (!ok) { set_err(std::string("bad or damaged checkpoint ") + path); return -1; }
+    return 0;
+}
+
 uint64_t pth_frame_hash(uint64_t key) {
     key = (~key) + (key << 21);
     key ^= key >> 24;

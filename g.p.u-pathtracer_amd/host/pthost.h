@@ -94,6 +94,27 @@ const int32_t* pth_bvh_index(const pth_bvh* b);      size_t pth_bvh_n_index(cons
 void pth_bvh_get_stats(const pth_bvh* b, pth_bvh_stats* out);
 void pth_bvh_free(pth_bvh* b);
 
+/* ---- image output + progressive-state checkpoints ----
+ * The reference only copies dev_drawRes into a GL texture (BasicScene.cpp:424-432).  Rows are
+ * stored bottom-up in the frame buffers (row 0 = bottom of the picture, as GL has it).
+ *   pth_write_ppm / pth_write_png : the display words (0x00BBGGRR, rgbToUint cudaUtils.h:99-105),
+ *                                   written top row first; PNG uses stored (uncompressed) deflate
+ *   pth_write_pfm                 : the float accumulator (PFM "PF", little endian, bottom-up)
+ *   pth_checkpoint_save / _load   : accumulator + the loop state needed to continue a progressive
+ *                                   render bit-identically: next frame number and constantPdf */
+int pth_write_ppm(const char* path, const uint32_t* rgba, int width, int height);
+int pth_write_png(const char* path, const uint32_t* rgba, int width, int height);
+int pth_write_pfm(const char* path, const float* accum, int width, int height);
+typedef struct pth_checkpoint_info {
+    int32_t width, height;
+    uint64_t next_frame;      /* frameNumber of the next launch (BasicScene.cpp:397)  */
+    uint64_t constant_pdf;    /* samples folded so far (BasicScene.cpp:399)          */
+    uint64_t scene_tag;       /* caller's fingerprint of scene + parameters          */
+} pth_checkpoint_info;
+int pth_checkpoint_save(const char* path, const pth_checkpoint_info* info, const float* accum);
+/* reads the header; if accum is non-NULL also the pixels (width*height*3 floats, caller's buffer) */
+int pth_checkpoint_load(const char* path, pth_checkpoint_info* info, float* accum);
+
 /* uf::hash (utilfun.cpp:380-389): the per-frame seed the App loop passes down. */
 uint64_t pth_frame_hash(uint64_t frame);
 
