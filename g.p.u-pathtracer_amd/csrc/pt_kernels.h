@@ -685,6 +685,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     } else if (geom == 0) {
         n = vnormalize(h.n);
         nl = n;  // tracer.cu:126-127
+        if ((P.flags & PT_FLAG_FACE_FORWARD) && !(vdot(n, d) < 0)) nl = vscale(n, -1.0f);
         if (P.tri_matid) {  // extension: per-triangle material row
             const int row = P.tri_matid[h.tri];
             const float4 m0 = P.mat_table[2 * row], m1 = P.mat_table[2 * row + 1];
@@ -703,17 +704,31 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     }
     accu = vadd(accu, vmul(mask, emit));
 
+    if ((P.flags & PT_FLAG_RUSSIAN_ROULETTE) && ps.depth >= 2) {  // extension
+        const float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
+        if (!(pt_rng_next(rng) < pr)) { col_out = accu; return true; }
+        objcol = vscale(objcol, 1.0f / pr);
+    }
+
     v3 nextdir;
     if (mat == PT_MAT_DIFF) {  // tracer.cu:156-186
-        (void)pt_rng_next(rng);
-        (void)pt_rng_next(rng);
+        if (!(P.flags & PT_FLAG_COSINE_DIFF)) {
+            (void)pt_rng_next(rng);
+            (void)pt_rng_next(rng);
+        }
         v3 nt = fabsf(nl.x) > fabsf(nl.y) ? V3(nl.z, 0.f, -nl.x) : V3(0.f, -nl.z, nl.y);
         nt = vnormalize(nt);
         const v3 nb = vnormalize(vcross(nl, nt));
         const float f1 = pt_rng_next(rng), f2 = pt_rng_next(rng);
         float c, s;
         pt_sincos2pi(f1, c, s);
-        const v3 rv = V3(c * f2, sqrtf(1.0f - f2 * f2), s * f2);  // cudaUtils.h:185-192
+        v3 rv;
+        if (P.flags & PT_FLAG_COSINE_DIFF) {  // extension: pdf = cos/pi
+            const float r2s = sqrtf(f2);
+            rv = V3(c * r2s, sqrtf(1.0f - f2), s * r2s);
+        } else {
+            rv = V3(c * f2, sqrtf(1.0f - f2 * f2), s * f2);  // cudaUtils.h:185-192
+        }
         nextdir = vnormalize(vmadd(nt, rv.z, vmadd(nl, rv.y, vscale(nb, rv.x))));
         hitpos = vmadd(nl, 0.001f, hitpos);
         mask = vmul(mask, objcol);
@@ -733,20 +748,24 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         } else {
             const float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
             const v3 tdir = vnormalize(vmadd(n, -k, vscale(d, nnt)));
-            const float R0 = (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc);  // sic, :230
+            const bool fix = (P.flags & PT_FLAG_GLASS_FIX) != 0;  // extension
+            const float R0 = fix ? ((ntt - nc) * (ntt - nc)) / ((ntt + nc) * (ntt + nc))
+                                 : (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc);  // sic, :230
             const float c = 1.0f - (into ? -ddn : vdot(tdir, n));
             const float Re = R0 + (1.0f - R0) * c * c * c * c * c;
             const float Tr = 1 - Re;
             const float Pp = 0.25f + 0.5f * Re;
             const float RP = Re / Pp, TP = Tr / (1.0f - Pp);
-            if (pt_rng_next(rng) < 0.2f) {
+            bool transmitted = false;
+            if (pt_rng_next(rng) < (fix ? Pp : 0.2f)) {
                 mask = vscale(mask, RP);
                 nextdir = vnormalize(vmadd(n, -2.0f * vdot(n, d), d));
             } else {
                 mask = vscale(mask, TP);
                 nextdir = vnormalize(tdir);
+                transmitted = true;
             }
-            hitpos = vmadd(nl, 0.001f, hitpos);
+            hitpos = vmadd(nl, (fix && transmitted) ? -0.001f : 0.001f, hitpos);
         }
     } else {  // METAL :257-293
         const float f1 = pt_rng_next(rng), r2 = pt_rng_next(rng);

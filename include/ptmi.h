@@ -59,7 +59,21 @@ enum {
      * Default (flag clear) is the intended  w1*cos(theta)  (SURVEY.md §3.4 table). */
     PT_FLAG_METAL_LITERAL_W = 1u << 0,
     /* also write the 0x00BBGGRR display word (tracer.cu:394-398); needs rgba_dev. */
-    PT_FLAG_WRITE_RGBA = 1u << 1
+    PT_FLAG_WRITE_RGBA = 1u << 1,
+    /* Corrected-estimator switches — EXTENSIONS, all off by default so that the default path is the
+     * reference's arithmetic, quirks included.  Oracle: same flags. */
+    PT_FLAG_FACE_FORWARD = 1u << 2,  /* triangles: nl = dot(n,d) < 0 ? n : -n — what tracer.cu:126-127
+                                        computes and then discards (nl = n in the reference)           */
+    PT_FLAG_COSINE_DIFF = 1u << 3,   /* DIFF lobe: cosine-weighted direction from TWO draws (smallpt's
+                                        estimator; mask *= col is then exact) instead of the reference's
+                                        uniform hemisphere with no cosine term and two discarded draws
+                                        (tracer.cu:159-186)                                            */
+    PT_FLAG_GLASS_FIX = 1u << 4,     /* REFR: R0 = ((nt-nc)/(nt+nc))^2 (the reference's :230 multiplies
+                                        where it should divide), reflection chosen with probability
+                                        P = .25 + .5 Re (the weights RP/TP assume it; the reference
+                                        uses 0.2), transmitted rays start on the far side (-nl)       */
+    PT_FLAG_RUSSIAN_ROULETTE = 1u << 5 /* from the 3rd segment on: continue with probability
+                                        p = max(col) and divide col by p, else end the path          */
 };
 
 /* pt_ctx kernel selection (pt_set_option PT_OPT_KERNEL) */

@@ -425,6 +425,7 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
         } else if (geom == 0) {
             n = vnormalize(h.n);
             nl = n; /* tracer.cu:126-127: the flip is a discarded expression */
+            if ((P->flags & PT_FLAG_FACE_FORWARD) && !(vdot(n, d) < 0)) nl = vscale(n, -1.0f); /* extension */
             objcol = tricol; emit = triemi; mat = P->tri_mat;
             if (mtab) { /* extension (ptmi.h pt_upload_tri_materials): per-triangle material row */
                 const pt_material* m = &mtab[tri_mat[h.tri]];
@@ -438,16 +439,30 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
         }
         accu = vadd(accu, vmul(mask, emit));
 
+        if ((P->flags & PT_FLAG_RUSSIAN_ROULETTE) && depth >= 2) { /* extension (ptmi.h) */
+            float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
+            if (!(rng_next(rng) < pr)) return accu;
+            objcol = vscale(objcol, 1.0f / pr);
+        }
+
         v3 nextdir;
         if (mat == PT_MAT_DIFF) { /* tracer.cu:156-186 */
-            (void)rng_next(rng); (void)rng_next(rng); /* phi, r2: drawn, unused (:159-161) */
+            if (!(P->flags & PT_FLAG_COSINE_DIFF)) {
+                (void)rng_next(rng); (void)rng_next(rng); /* phi, r2: drawn, unused (:159-161) */
+            }
             v3 nt = fabsf(nl.x) > fabsf(nl.y) ? V(nl.z, 0, -nl.x) : V(0, -nl.z, nl.y);
             nt = vnormalize(nt);
             v3 nb = vnormalize(vcross(nl, nt));
             float f1 = rng_next(rng), f2 = rng_next(rng);
             float c, s;
             orc_sincos2pi(f1, &c, &s);
-            v3 rv = V(c * f2, sqrtf(1.0f - f2 * f2), s * f2); /* cudaUtils.h:185-192 */
+            v3 rv;
+            if (P->flags & PT_FLAG_COSINE_DIFF) { /* extension: cosine-weighted, pdf = cos/pi */
+                float r2s = sqrtf(f2);
+                rv = V(c * r2s, sqrtf(1.0f - f2), s * r2s);
+            } else {
+                rv = V(c * f2, sqrtf(1.0f - f2 * f2), s * f2); /* cudaUtils.h:185-192 */
+            }
             nextdir = vmadd(nt, rv.z, vmadd(nl, rv.y, vscale(nb, rv.x)));
             nextdir = vnormalize(nextdir);
             hitpos = vmadd(nl, 0.001f, hitpos);
@@ -468,20 +483,24 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             } else {
                 float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
                 v3 tdir = vnormalize(vmadd(n, -k, vscale(d, nnt)));
-                float R0 = (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc); /* sic, :230 */
+                int fix = (P->flags & PT_FLAG_GLASS_FIX) != 0; /* extension (ptmi.h) */
+                float R0 = fix ? ((ntt - nc) * (ntt - nc)) / ((ntt + nc) * (ntt + nc))
+                               : (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc); /* sic, :230 */
                 float c = 1.0f - (into ? -ddn : vdot(tdir, n));
                 float Re = R0 + (1.0f - R0) * c * c * c * c * c;
                 float Tr = 1 - Re;
                 float Pp = 0.25f + 0.5f * Re;
                 float RP = Re / Pp, TP = Tr / (1.0f - Pp);
-                if (rng_next(rng) < 0.2f) { /* (double)u < 0.2  <=>  u < 0.2f for binary32 u */
+                int transmitted = 0;
+                if (rng_next(rng) < (fix ? Pp : 0.2f)) { /* (double)u < 0.2  <=>  u < 0.2f for binary32 u */
                     mask = vscale(mask, RP);
                     nextdir = vnormalize(vmadd(n, -2.0f * vdot(n, d), d));
                 } else {
                     mask = vscale(mask, TP);
                     nextdir = vnormalize(tdir);
+                    transmitted = 1;
                 }
-                hitpos = vmadd(nl, 0.001f, hitpos);
+                hitpos = vmadd(nl, (fix && transmitted) ? -0.001f : 0.001f, hitpos);
             }
         } else { /* METAL :257-293 */
             float f1 = rng_next(rng), r2 = rng_next(rng);

@@ -210,3 +210,78 @@ def test_gpu_material_upload_errors(pt):
         pt.upload_bvh(g.Bvh(g.scene_mesh("bunny_low")))                         # more triangles than the table covers
     pt.upload_tri_materials(None, None)
     pt.upload_bvh(g.Bvh(g.scene_mesh("bunny_low")))
+
+
+# ------------------------------------------------------------------------------ estimator switches
+ALL_FIXES = g.FLAG_FACE_FORWARD | g.FLAG_COSINE_DIFF | g.FLAG_GLASS_FIX | g.FLAG_RUSSIAN_ROULETTE
+
+
+def test_oracle_estimator_switches():
+    """PT_FLAG_FACE_FORWARD / COSINE_DIFF / GLASS_FIX / RUSSIAN_ROULETTE (extensions, default off)."""
+    mesh = g.scene_mesh("cornell_box")
+    bvh = g.Bvh(mesh)
+    W, H = 160, 120
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.bk_color[:] = (0, 0, 0)
+    p.depth = 6
+    kw = dict(materials=mesh.materials, tri_material=mesh.tri_material)
+    base, _, cb = orc.render(bvh, None, cam, p, 32, **kw)
+    # Russian roulette keeps the expectation — checked in a CLOSED room (the reference spheres, dimmed):
+    # in an open scene the reference returns bkColor and DROPS the path's radiance on a miss
+    # (tracer.cu:140-142), so ending paths early changes the picture there by construction.
+    room = g.reference_spheres()
+    for sp in room:
+        sp.emi[:] = [0.1 * e for e in sp.emi]
+    full, _, cf = orc.render(bvh, room, cam, p, 32, **kw)
+    p.flags = g.FLAG_RUSSIAN_ROULETTE
+    rr, _, cr = orc.render(bvh, room, cam, p, 32, **kw)
+    assert cr["rays"] < 0.8 * cf["rays"]                        # paths really end early
+    assert abs(rr.mean() - full.mean()) < 0.03 * full.mean()    # ... without changing the expectation
+    p.flags = g.FLAG_COSINE_DIFF
+    cosw, _, _ = orc.render(bvh, None, cam, p, 32, **kw)
+    assert np.any(cosw != base) and 0.3 * base.mean() < cosw.mean() < 3 * base.mean()
+    # face-forward: seen from behind (cull off), a one-sided wall shades with the flipped normal
+    p.flags, p.cull_backfaces = 0, 0
+    cam.pos[:] = (0, 0, -90)                                    # behind the back wall, looking +z
+    cam.front[:] = (0, 0, 1)
+    cam.right[:] = (-1, 0, 0)
+    a0, _, _ = orc.render(bvh, None, cam, p, 8, **kw)
+    p.flags = g.FLAG_FACE_FORWARD
+    a1, _, _ = orc.render(bvh, None, cam, p, 8, **kw)
+    assert np.any(a0 != a1)
+    # glass: the fixed R0 is the textbook 0.04-ish value, the reference's is (nt-nc)^2 (sic): images differ
+    glass = [material((1, 1, 1), mat=g.MAT_REFR)] + list(mesh.materials)
+    ids = mesh.tri_material + 1
+    ids[10:22] = 0                                              # the short box becomes glass
+    cam2, p2 = g.default_camera(W, H), g.default_params(W, H)
+    p2.bk_color[:] = (0, 0, 0)
+    p2.depth = 6
+    g0, _, _ = orc.render(bvh, None, cam2, p2, 16, materials=glass, tri_material=ids)
+    p2.flags = g.FLAG_GLASS_FIX | g.FLAG_FACE_FORWARD
+    g1, _, _ = orc.render(bvh, None, cam2, p2, 16, materials=glass, tri_material=ids)
+    assert np.any(g0 != g1) and np.isfinite(g1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [g.FLAG_FACE_FORWARD, g.FLAG_COSINE_DIFF, g.FLAG_GLASS_FIX, g.FLAG_RUSSIAN_ROULETTE, ALL_FIXES],
+                         ids=["face-forward", "cosine-diff", "glass-fix", "russian-roulette", "all"])
+def test_gpu_equals_oracle_with_estimator_switches(pt, flags):
+    mesh = g.scene_mesh("cornell_box_dragon")
+    bvh = g.Bvh(mesh)
+    table = [material((1, 1, 1), mat=g.MAT_REFR), material((0.9, 0.9, 0.9), mat=g.MAT_SPEC)] + list(mesh.materials)
+    ids = mesh.tri_material + 2
+    ids[10:22] = 0                      # short box: glass
+    ids[22:34] = 1                      # tall box: mirror
+    W, H = 400, 300
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.depth, p.frame, p.cull_backfaces = 7, 2, 0
+    p.bk_color[:] = (0.02, 0.02, 0.05)
+    p.flags = flags | g.FLAG_WRITE_RGBA
+    for sph in (None, g.reference_spheres()):
+        ref, rref, cnt = orc.render(bvh, sph, cam, p, 3, materials=table, tri_material=ids)
+        a, r = _gpu(pt, bvh, sph, cam, p, 3, table, ids)
+        n_diff = int(np.any(a != ref, axis=-1).sum())
+        print(f"flags {flags:#x} spheres {sph is not None}: differing pixels {n_diff}, rays/path {cnt['rays'] / cnt['paths']:.2f}")
+        assert n_diff <= pt.max_diff
+        if n_diff == 0:
+            assert np.array_equal(r, rref)
