@@ -95,6 +95,8 @@ PTMI_SYMBOLS = [
     ("pt_upload_spheres", _i, [_vp, C.POINTER(Sphere), _sz]),
     ("pt_render", _i, [_vp, _vp, _vp, C.POINTER(Camera), C.POINTER(Params), _u32]),
     ("pt_trace_rays", _i, [_vp, _vp, _sz, _i, _vp, _vp, _vp]),
+    ("pt_build_bvh", _i, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    ("pt_last_build_ms", _i, [_vp, C.POINTER(C.c_float)]),
     ("pt_upload_tri_materials", _i, [_vp, C.POINTER(Material), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t]),
     ("pt_get_counters", _i, [_vp, C.POINTER(Counters)]),
     ("pt_get_wave_stats", _i, [_vp, C.POINTER(C.c_uint64), _i]),

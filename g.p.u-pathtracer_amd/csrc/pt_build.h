@@ -1,0 +1,311 @@
+// pt_build.h — BVH construction ON the device (pt_build_bvh): the step in front
+// of the hot path.  The reference builds on the host (SplitBVHBuilder.cpp, 1.7 s per 100 k
+// triangles) and so does host/pthost.cpp (SAH/SBVH, ~1.4 s for 800 k); this is the fast
+// alternative for scenes that change: a linear BVH
+//   1. k_tri_bounds   triangle boxes + bounds of the box centres (ordered-int atomics)
+//   2. k_morton       63-bit Morton key of every centre (21 bits per axis)
+//   3. hipcub radix sort of (key, triangle)
+//   4. k_hierarchy    Karras 2012: every inner node finds its key range and split in parallel;
+//                     equal keys are told apart by their position, so the tree stays a tree
+//   5. k_fit          bottom-up boxes: the second thread to arrive at a node merges its children
+//   6. k_records      the 64-byte triangle records in sorted order; a subtree with <= leaf_max
+//                     triangles is ONE leaf (its records are contiguous), the last one flagged
+//   7. k_binary       the binary nodes in the Compact layout (walks 0/1, pt_trace_rays)
+//   8. k_collapse     level by level: 4-wide nodes (largest-area inner child opened first) with
+//                     8-bit outward-rounded boxes — pt_encode_wide_node, the host path's encoder
+// The product is the same item buffer pt_upload_bvh makes ([binary nodes][records][wide nodes]),
+// so every kernel and every parity property (exact triangle test, ties to the smaller id: the
+// closest hit does not depend on the tree) carries over; only the tree QUALITY differs (no SAH).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "pt_items.h"
+
+#define PTB_BLOCK 256
+
+struct BuildArrays {
+    // inputs
+    const float* verts;      // [n_verts][3]
+    const int* tris;         // [n][3]
+    int n;                   // triangles (>= 2)
+    int n_orig;              // caller's triangle count (1 when the lone triangle was doubled to get a tree)
+    int leaf_max;            // subtree size that becomes one leaf (>= 1)
+    // per triangle (unsorted): box
+    float* tbox;             // [n][6] lo xyz, hi xyz
+    unsigned int* cbounds;   // [6] ordered-int min xyz / max xyz of the box centres
+    // sorted order
+    unsigned long long* key_in; unsigned long long* key; // [n]
+    int* val_in; int* val;                               // [n] triangle id
+    // hierarchy (inner node i in [0, n-1), leaf j in [0, n))
+    int* left; int* right;   // child: >= 0 inner node, < 0 ~leaf position
+    int* first; int* last;   // key range of the inner node
+    int* parent_i;           // parent of inner node (root: -1)
+    int* parent_l;           // parent of leaf position
+    float* nbox;             // [n-1][6] box of the inner node
+    unsigned int* arrive;    // [n-1] fit counters
+    // outputs
+    float4* items;           // [binary nodes n-1][records n][wide nodes <= n-1]
+    unsigned int* stats;     // [0] wide nodes allocated [1] next-frontier size [2] leaves [3] max binary depth
+    int2* frontier_a; int2* frontier_b;   // (inner node, wide slot)
+};
+
+__device__ __forceinline__ unsigned int ptb_ordered(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ptb_unordered(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_tri_bounds(const BuildArrays B) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    float c[3] = {0.f, 0.f, 0.f};
+    const bool live = i < B.n;
+    if (live) {
+        const int i0 = B.tris[3 * i], i1 = B.tris[3 * i + 1], i2 = B.tris[3 * i + 2];
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            const float x = B.verts[3 * (size_t)i0 + a], y = B.verts[3 * (size_t)i1 + a], z = B.verts[3 * (size_t)i2 + a];
+            lo[a] = fminf(x, fminf(y, z));
+            hi[a] = fmaxf(x, fmaxf(y, z));
+            c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+            B.tbox[6 * (size_t)i + a] = lo[a];
+            B.tbox[6 * (size_t)i + 3 + a] = hi[a];
+        }
+    }
+    // wave reduction, then one atomic per wave and component
+    for (int a = 0; a < 3; a++) {
+        unsigned int mn = live ? ptb_ordered(c[a]) : 0xffffffffu, mx = live ? ptb_ordered(c[a]) : 0u;
+        for (int off = 32; off > 0; off >>= 1) {
+            mn = min(mn, (unsigned int)__shfl_xor((int)mn, off));
+            mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&B.cbounds[a], mn);
+            atomicMax(&B.cbounds[3 + a], mx);
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long ptb_spread21(unsigned int v) {  // bit i -> bit 3i
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_morton(const BuildArrays B) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= B.n) return;
+    unsigned int q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = ptb_unordered(B.cbounds[a]), hi = ptb_unordered(B.cbounds[3 + a]);
+        const float c = 0.5f * B.tbox[6 * (size_t)i + a] + 0.5f * B.tbox[6 * (size_t)i + 3 + a];
+        const float ext = hi - lo;
+        float u = ext > 0.f ? (c - lo) / ext : 0.f;
+        u = fminf(fmaxf(u, 0.f), 1.f);
+        q[a] = min((unsigned int)(u * 2097152.0f), 2097151u);
+    }
+    B.key_in[i] = (ptb_spread21(q[0]) << 2) | (ptb_spread21(q[1]) << 1) | ptb_spread21(q[2]);
+    B.val_in[i] = i;
+}
+
+// common-prefix length of sorted positions i and j (-1 outside the array); equal keys are
+// separated by the position itself (Karras 2012, section 4)
+__device__ __forceinline__ int ptb_delta(const unsigned long long* key, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long x = key[i] ^ key[j];
+    if (x == 0) return 64 + __clz((unsigned int)(i ^ j));
+    return __clzll((long long)x);
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_hierarchy(const BuildArrays B) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    const int n = B.n;
+    if (i >= n - 1) return;
+    const unsigned long long* key = B.key;
+    const int d = ptb_delta(key, n, i, i + 1) - ptb_delta(key, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = ptb_delta(key, n, i, i - d);
+    int lmax = 2;
+    while (ptb_delta(key, n, i, i + lmax * d) > dmin) lmax <<= 1;   // lmax <= 2n: i + lmax*d leaves [0,n) first
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (ptb_delta(key, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = ptb_delta(key, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (ptb_delta(key, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const int cl = lo == gamma ? ~gamma : gamma;
+    const int cr = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
+    B.left[i] = cl; B.right[i] = cr;
+    B.first[i] = lo; B.last[i] = hi;
+    if (cl >= 0) B.parent_i[cl] = i; else B.parent_l[~cl] = i;
+    if (cr >= 0) B.parent_i[cr] = i; else B.parent_l[~cr] = i;
+    if (i == 0) B.parent_i[0] = -1;
+}
+
+__device__ __forceinline__ void ptb_child_box(const BuildArrays& B, int c, float* bx) {
+    const float* src = c >= 0 ? B.nbox + 6 * (size_t)c : B.tbox + 6 * (size_t)B.val[~c];
+    for (int a = 0; a < 6; a++) bx[a] = src[a];
+}
+
+// One thread per leaf walks towards the root; at every inner node the FIRST arrival stops and
+// the second — which therefore knows both children are finished — merges their boxes.
+__global__ void __launch_bounds__(PTB_BLOCK) k_fit(const BuildArrays B) {
+    const int j = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (j >= B.n) return;
+    int cur = B.parent_l[j];
+    while (cur >= 0) {
+        __threadfence();                                   // my child's box is visible before I announce it
+        if (atomicAdd(&B.arrive[cur], 1u) == 0u) return;
+        __threadfence();                                   // the sibling's box is visible after its announcement
+        float a[6], b[6];
+        ptb_child_box(B, B.left[cur], a);
+        ptb_child_box(B, B.right[cur], b);
+        float* dst = B.nbox + 6 * (size_t)cur;
+        for (int k = 0; k < 3; k++) {
+            dst[k] = fminf(a[k], b[k]);
+            dst[3 + k] = fmaxf(a[k + 3], b[k + 3]);
+        }
+        cur = B.parent_i[cur];
+    }
+}
+
+// depth of every leaf (edges to the root), for the stack bound
+__global__ void __launch_bounds__(PTB_BLOCK) k_depth(const BuildArrays B) {
+    const int j = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    unsigned int depth = 0;
+    if (j < B.n) {
+        int cur = B.parent_l[j];
+        while (cur >= 0) { depth++; cur = B.parent_i[cur]; }
+    }
+    for (int off = 32; off > 0; off >>= 1) depth = max(depth, (unsigned int)__shfl_xor((int)depth, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&B.stats[3], depth);
+}
+
+// true when inner node c is cut into ONE leaf (its <= leaf_max records are contiguous)
+__device__ __forceinline__ bool ptb_is_cut(const BuildArrays& B, int c) {
+    return c > 0 && B.last[c] - B.first[c] + 1 <= B.leaf_max;
+}
+
+// link of child c as the walks read it, given where the records start (float4 index)
+__device__ __forceinline__ bool ptb_child_is_leaf(const BuildArrays& B, int c, int& first_pos) {
+    if (c < 0) { first_pos = ~c; return true; }
+    if (ptb_is_cut(B, c)) { first_pos = B.first[c]; return true; }
+    return false;
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_records(const BuildArrays B) {
+    const int j = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (j >= B.n) return;
+    // the leaf this record belongs to: the topmost cut ancestor, or the record alone
+    int end = j;
+    for (int p = B.parent_l[j]; p > 0 && ptb_is_cut(B, p); p = B.parent_i[p]) end = B.last[p];
+    const int last = j == end ? 1 : 0;
+    if (last) atomicAdd(&B.stats[2], 1u);
+    const int t = B.val[j];
+    const int i0 = B.tris[3 * (size_t)t], i1 = B.tris[3 * (size_t)t + 1], i2 = B.tris[3 * (size_t)t + 2];
+    float v0[3], v1[3], v2[3], rec[16];
+    for (int a = 0; a < 3; a++) {
+        v0[a] = B.verts[3 * (size_t)i0 + a];
+        v1[a] = B.verts[3 * (size_t)i1 + a];
+        v2[a] = B.verts[3 * (size_t)i2 + a];
+    }
+    if (v0[0] == 0.f) v0[0] = 0.f;   // -0.0f -> +0.0f, as the Compact producer stores it (host/pthost.cpp)
+    pt_encode_record(v0, v1, v2, min(t, B.n_orig - 1), last, rec);
+    float4* dst = B.items + 4 * (size_t)(B.n - 1) + 4 * (size_t)j;
+    for (int k = 0; k < 4; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
+}
+
+// binary nodes, Compact layout (CudaBVH.cpp:221-224): [c0.lo.x c0.hi.x c0.lo.y c0.hi.y]
+// [c1 ...] [c0.lo.z c0.hi.z c1.lo.z c1.hi.z] [link0 link1 0 0]; inner node i at float4 index 4i
+__global__ void __launch_bounds__(PTB_BLOCK) k_binary(const BuildArrays B) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= B.n - 1) return;
+    const int rec_base = 4 * (B.n - 1);
+    float d[16];
+    const int ch[2] = {B.left[i], B.right[i]};
+    for (int k = 0; k < 2; k++) {
+        float bx[6];
+        ptb_child_box(B, ch[k], bx);
+        d[0 + 4 * k] = bx[0]; d[1 + 4 * k] = bx[3];
+        d[2 + 4 * k] = bx[1]; d[3 + 4 * k] = bx[4];
+        d[8 + 2 * k] = bx[2]; d[9 + 2 * k] = bx[5];
+        int fp;
+        d[12 + k] = pt_i2f(ptb_child_is_leaf(B, ch[k], fp) ? ~(rec_base + 4 * fp) : 4 * ch[k]);
+    }
+    d[14] = 0.f; d[15] = 0.f;
+    float4* dst = B.items + 4 * (size_t)i;
+    for (int k = 0; k < 4; k++) dst[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+}
+
+__device__ __forceinline__ float ptb_area(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+
+// One level of the 4-wide tree: every frontier entry (inner node, wide slot) adopts up to four
+// descendants — the inner child with the largest box is opened first, as the host path does —
+// writes its node and queues its inner children for the next level.
+__global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, const int2* __restrict__ in, int n_in, int2* __restrict__ out) {
+    const int idx = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (idx >= n_in) return;
+    const int2 item = in[idx];
+    const int rec_base = 4 * (B.n - 1);
+    const int wide_base = rec_base + 4 * B.n;
+    int ref[4];
+    PtBox cb[4];
+    int cnt = 0;
+    auto add = [&](int c) {
+        float bx[6];
+        ptb_child_box(B, c, bx);
+        for (int a = 0; a < 3; a++) { cb[cnt].lo[a] = bx[a]; cb[cnt].hi[a] = bx[3 + a]; }
+        ref[cnt] = c;
+        cnt++;
+    };
+    add(B.left[item.x]);
+    add(B.right[item.x]);
+    while (cnt < 4) {
+        int best = -1;
+        float ba = -1.f;
+        for (int k = 0; k < cnt; k++) {
+            int fp;
+            if (ptb_child_is_leaf(B, ref[k], fp)) continue;
+            const float bx[6] = {cb[k].lo[0], cb[k].lo[1], cb[k].lo[2], cb[k].hi[0], cb[k].hi[1], cb[k].hi[2]};
+            const float ar = ptb_area(bx);
+            if (ar > ba) { ba = ar; best = k; }
+        }
+        if (best < 0) break;
+        const int v = ref[best];
+        cb[best] = cb[cnt - 1];
+        ref[best] = ref[cnt - 1];
+        cnt--;
+        add(B.left[v]);
+        add(B.right[v]);
+    }
+    int32_t link[4] = {0, 0, 0, 0};
+    for (int k = 0; k < cnt; k++) {
+        int fp;
+        if (ptb_child_is_leaf(B, ref[k], fp)) {
+            link[k] = ~(rec_base + 4 * fp);
+        } else {
+            const int slot = (int)atomicAdd(&B.stats[0], 1u);
+            link[k] = wide_base + 4 * slot;
+            out[atomicAdd(&B.stats[1], 1u)] = make_int2(ref[k], slot);
+        }
+    }
+    float d[16];
+    pt_encode_wide_node(cb, cnt, link, d);
+    float4* dst = B.items + (size_t)wide_base + 4 * (size_t)item.y;
+    for (int k = 0; k < 4; k++) dst[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+}

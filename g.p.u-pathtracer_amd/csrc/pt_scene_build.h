@@ -29,6 +29,8 @@
 #include <string>
 #include <vector>
 
+#include "pt_items.h"
+
 namespace ptscene {
 
 struct Box3 {
@@ -266,10 +268,8 @@ inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false) 
                                                N[0], N[1], N[2], i2f((int32_t)(((uint32_t)r.id << 1) | (uint32_t)last))};
                         out.rec.insert(out.rec.end(), rec, rec + 16);
                     } else {
-                        const float rec[16] = {v0[0], v0[1], v0[2], i2f(r.id),
-                                               v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], i2f(last),
-                                               v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.f,
-                                               N[0], N[1], N[2], 0.f};
+                        float rec[16];
+                        pt_encode_record(v0, v1, v2, r.id, last, rec);
                         out.rec.insert(out.rec.end(), rec, rec + 16);
                     }
                 }
@@ -370,43 +370,14 @@ inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false) 
         for (size_t oi = 0; oi < order.size(); oi++) {
             const WNode& w = W[order[oi]];
             float* d = &out.wide[16 * oi];
-            Box3 nb = w.cb[0];
-            for (int k = 1; k < w.n; k++) nb.grow(w.cb[k]);
-            uint32_t q[6] = {0, 0, 0, 0, 0, 0};
-            uint32_t meta = (uint32_t)w.n << 24;
-            for (int a = 0; a < 3; a++) {
-                const float origin = nb.lo[a];
-                const float ext = nb.hi[a] - nb.lo[a];
-                int e = 1;
-                if (ext > 0.f) {
-                    int x;
-                    std::frexp((double)ext / 255.0, &x);  // ext/255 = m 2^x, m in [0.5,1) => 2^x >= ext/255
-                    e = x + 127;
-                }
-                e = std::min(254, std::max(1, e));
-                while (e < 254 && std::fmaf(255.f, i2f(e << 23), origin) < nb.hi[a]) e++;
-                const float scale = i2f(e << 23);
-                meta |= (uint32_t)e << (8 * a);
-                for (int k = 0; k < 4; k++) {
-                    int qlo = 255, qhi = 0;
-                    if (k < w.n) {
-                        qlo = (int)std::min(255.0, std::max(0.0, std::floor(((double)w.cb[k].lo[a] - (double)origin) / (double)scale)));
-                        qhi = (int)std::min(255.0, std::max(0.0, std::ceil(((double)w.cb[k].hi[a] - (double)origin) / (double)scale)));
-                        while (qlo > 0 && std::fmaf((float)qlo, scale, origin) > w.cb[k].lo[a]) qlo--;
-                        while (qhi < 255 && std::fmaf((float)qhi, scale, origin) < w.cb[k].hi[a]) qhi++;
-                    }
-                    q[a] |= (uint32_t)qlo << (8 * k);
-                    q[3 + a] |= (uint32_t)qhi << (8 * k);
-                }
-            }
             int32_t link[4] = {0, 0, 0, 0};
             for (int k = 0; k < w.n; k++)
                 link[k] = w.child[k] >= 0 ? (int32_t)(wide_base + 4 * pos[(size_t)w.child[k]])
                                           : ~(int32_t)(rec_base + (size_t)leaf_first[~(int32_t)w.child[k]]);
-            d[0] = nb.lo[0]; d[1] = nb.lo[1]; d[2] = nb.lo[2]; d[3] = i2f((int32_t)meta);
-            d[4] = i2f((int32_t)q[0]); d[5] = i2f((int32_t)q[1]); d[6] = i2f((int32_t)q[2]); d[7] = i2f((int32_t)q[3]);
-            d[8] = i2f((int32_t)q[4]); d[9] = i2f((int32_t)q[5]); d[10] = i2f(link[0]); d[11] = i2f(link[1]);
-            d[12] = i2f(link[2]); d[13] = i2f(link[3]);
+            PtBox cb[4];
+            for (int k = 0; k < w.n; k++)
+                for (int a = 0; a < 3; a++) { cb[k].lo[a] = w.cb[k].lo[a]; cb[k].hi[a] = w.cb[k].hi[a]; }
+            pt_encode_wide_node(cb, w.n, link, d);
         }
     }
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -14,6 +15,7 @@
 #include "../../include/ptmi.h"
 #include "pt_kernels.h"
 #include "pt_scene_build.h"
+#include "pt_build.h"
 
 static_assert(sizeof(pt_sphere) == 44, "pt_sphere must match the reference Sphere (44 B)");
 static_assert(sizeof(pt_sphere_d) == sizeof(pt_sphere), "device sphere mirror");
@@ -22,6 +24,21 @@ static_assert(sizeof(pt_params) == 104 && sizeof(pt_camera) == 64 && sizeof(pt_c
 namespace {
 thread_local std::string g_err;
 }
+
+namespace {
+struct DevTemp {  // temporaries of one build, released together
+    std::vector<void*> ptrs;
+    ~DevTemp() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t get(T** out, size_t count) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = (T*)p;
+        return e;
+    }
+};
+}  // namespace
+
 
 struct pt_ctx {
     int device = 0;
@@ -45,6 +62,7 @@ struct pt_ctx {
     uint32_t wide_top_layout = 0, wide_depth = 0;
     uint64_t n_wide = 0;
     bool has_bvh = false;
+    float build_ms = -1.f;       // device time of the last pt_build_bvh
     // options
     int opt_kernel = PT_KERNEL_AUTO;
     int opt_counters = 0;
@@ -313,6 +331,143 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     c->scene_bytes = nb + tb + wb;
     c->max_tri_id = max_id;
     c->has_bvh = true;
+    return PT_OK;
+}
+
+// ---- pt_build_bvh: the BVH built on the device (pt_build.h) ---------------------------------
+int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris) {
+    if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    if (!verts || !tris || n_verts == 0 || n_tris == 0) return fail(c, PT_ERR_INVALID, "pt_build_bvh: empty mesh or null array");
+    if (n_tris > (1u << 27) || n_verts > (1u << 30)) return fail(c, PT_ERR_INVALID, "pt_build_bvh: mesh too large for 32-bit links");
+    if (c->opt_tri_test == 1) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: Woop records are made by the host path only (pt_upload_bvh)");
+    for (size_t i = 0; i < 3 * n_tris; i++)
+        if (tris[i] < 0 || (size_t)tris[i] >= n_verts) return fail(c, PT_ERR_INVALID, "pt_build_bvh: vertex index out of range");
+    for (size_t i = 0; i < 3 * n_verts; i++)
+        if (!(std::fabs(verts[i]) <= 3.0e38f)) return fail(c, PT_ERR_INVALID, "pt_build_bvh: non-finite vertex");
+    if (c->d_tri_matid && n_tris > c->n_tri_matid)
+        return fail(c, PT_ERR_INVALID, "pt_build_bvh: the triangle-material array on this context does not cover this mesh (clear or re-upload it first)");
+
+    // a lone triangle is doubled: the hierarchy needs two leaves (both report id 0)
+    std::vector<int32_t> two;
+    const int n = (int)std::max<size_t>(n_tris, 2);
+    if (n_tris == 1) { two.assign(tris, tris + 3); two.insert(two.end(), tris, tris + 3); tris = two.data(); }
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    DevTemp tmp;
+    BuildArrays B;
+    std::memset(&B, 0, sizeof B);
+    B.n = n;
+    B.n_orig = (int)n_tris;
+    B.leaf_max = std::max(1, c->opt_leaf_max ? c->opt_leaf_max : 1);
+    float* d_verts = nullptr;
+    int* d_tris_idx = nullptr;
+    HIP_TRY(c, tmp.get(&d_verts, 3 * n_verts));
+    HIP_TRY(c, tmp.get(&d_tris_idx, 3 * (size_t)n));
+    HIP_TRY(c, tmp.get(&B.tbox, 6 * (size_t)n));
+    HIP_TRY(c, tmp.get(&B.cbounds, 6));
+    HIP_TRY(c, tmp.get(&B.key_in, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.key, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.val_in, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.val, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.left, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.right, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.first, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.last, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.parent_i, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.parent_l, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.nbox, 6 * (size_t)n));
+    HIP_TRY(c, tmp.get(&B.arrive, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.stats, 4));
+    HIP_TRY(c, tmp.get(&B.frontier_a, (size_t)n));
+    HIP_TRY(c, tmp.get(&B.frontier_b, (size_t)n));
+    B.verts = d_verts;
+    B.tris = d_tris_idx;
+    const size_t n_items = (size_t)(n - 1) + (size_t)n + (size_t)(n - 1);   // binary, records, wide (upper bound)
+    if (n_items * 4 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_build_bvh: scene too large for 32-bit links");
+    float4* items = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&items, n_items * 64));
+    B.items = items;
+    struct ItemsGuard { float4* p; ~ItemsGuard() { if (p) (void)hipFree(p); } } guard{items};
+
+    hipStream_t st = c->stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
+    HIP_TRY(c, hipMemcpyAsync(d_verts, verts, 3 * n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_tris_idx, tris, 3 * (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const unsigned int cb0[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    const unsigned int st0[4] = {1u, 0u, 0u, 0u};   // wide slot 0 is the root's
+    HIP_TRY(c, hipMemcpyAsync(B.cbounds, cb0, sizeof cb0, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(B.stats, st0, sizeof st0, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(B.arrive, 0, (size_t)n * sizeof(unsigned int), st));
+    HIP_TRY(c, hipMemsetAsync(items, 0, n_items * 64, st));
+    HIP_TRY(c, hipEventRecord(e0, st));
+
+    const dim3 blk(PTB_BLOCK), grd((unsigned)((n + PTB_BLOCK - 1) / PTB_BLOCK));
+    hipLaunchKernelGGL(k_tri_bounds, grd, blk, 0, st, B);
+    hipLaunchKernelGGL(k_morton, grd, blk, 0, st, B);
+    size_t cub_bytes = 0;
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, B.key_in, B.key, B.val_in, B.val, n, 0, 63, st));
+    char* cub_tmp = nullptr;
+    HIP_TRY(c, tmp.get(&cub_tmp, cub_bytes));
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, B.key_in, B.key, B.val_in, B.val, n, 0, 63, st));
+    hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, B);
+    hipLaunchKernelGGL(k_fit, grd, blk, 0, st, B);
+    hipLaunchKernelGGL(k_depth, grd, blk, 0, st, B);
+    hipLaunchKernelGGL(k_records, grd, blk, 0, st, B);
+    hipLaunchKernelGGL(k_binary, grd, blk, 0, st, B);
+    HIP_TRY(c, hipGetLastError());
+    // 4-wide collapse, one launch per level of the wide tree
+    const int2 root_item = make_int2(0, 0);
+    HIP_TRY(c, hipMemcpyAsync(B.frontier_a, &root_item, sizeof root_item, hipMemcpyHostToDevice, st));
+    int n_in = 1;
+    uint32_t levels = 0;
+    int2 *fin = B.frontier_a, *fout = B.frontier_b;
+    while (n_in > 0) {
+        if (++levels > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
+        HIP_TRY(c, hipMemsetAsync(B.stats + 1, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_collapse, dim3((unsigned)((n_in + PTB_BLOCK - 1) / PTB_BLOCK)), blk, 0, st, B, fin, n_in, fout);
+        HIP_TRY(c, hipGetLastError());
+        unsigned int n_out = 0;
+        HIP_TRY(c, hipMemcpyAsync(&n_out, B.stats + 1, sizeof n_out, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (n_out > (unsigned)n) return fail(c, PT_ERR_DEVICE, "pt_build_bvh: frontier overflow");
+        n_in = (int)n_out;
+        std::swap(fin, fout);
+    }
+    HIP_TRY(c, hipEventRecord(e1, st));
+    unsigned int stats[4];
+    HIP_TRY(c, hipMemcpyAsync(stats, B.stats, sizeof stats, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    HIP_TRY(c, hipEventElapsedTime(&c->build_ms, e0, e1));
+    if (stats[3] > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
+
+    (void)hipFree(c->d_nodes);
+    c->d_nodes = items;
+    guard.p = nullptr;
+    c->d_tris = c->d_nodes;
+    c->records_woop = false;
+    c->wide_root = 4 * ((uint64_t)(n - 1) + (uint64_t)n);
+    c->wide_top_layout = 1;      // level order below the root, not a breadth-first prefix of fixed size
+    c->n_top_layout = 1;
+    c->wide_depth = levels;
+    c->n_wide = stats[0];
+    c->n_inner = (uint64_t)(n - 1);
+    c->n_refs = (uint64_t)n;
+    c->n_leaves = stats[2];
+    c->max_depth = stats[3];
+    c->scene_bytes = n_items * 64;
+    c->max_tri_id = (int32_t)n_tris - 1;
+    c->has_bvh = true;
+    return PT_OK;
+}
+
+int pt_last_build_ms(pt_ctx* c, float* ms) {
+    if (!c || !ms) return fail(c, PT_ERR_INVALID, "pt_last_build_ms: null argument");
+    if (c->build_ms < 0.f) return fail(c, PT_ERR_INVALID, "pt_last_build_ms: no pt_build_bvh on this context yet");
+    *ms = c->build_ms;
     return PT_OK;
 }
 

@@ -103,6 +103,16 @@ class PathTracer:
         n = len(spheres) if spheres is not None else 0
         self._check(self._lib.pt_upload_spheres(self._ctx, spheres if n else None, n))
 
+    def build_bvh(self, mesh):
+        """Build the BVH on the device from a Mesh (pt_build_bvh; extension).  Returns the device
+        build time in ms."""
+        v = np.ascontiguousarray(mesh.verts, np.float32)
+        t = np.ascontiguousarray(mesh.tris, np.int32)
+        self._check(self._lib.pt_build_bvh(self._ctx, v.ctypes.data, len(v), t.ctypes.data, len(t)))
+        ms = C.c_float()
+        self._check(self._lib.pt_last_build_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
     def upload_tri_materials(self, table, tri_material):
         """Per-triangle materials (extension): `table` = sequence of Material, `tri_material` =
         int32 row per ORIGINAL triangle id.  table=None clears (one global material again)."""

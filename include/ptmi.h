@@ -209,6 +209,16 @@ int pt_upload_bvh(pt_ctx* ctx,
                   const int32_t* tri_index, size_t n_index);
 int pt_upload_spheres(pt_ctx* ctx, const pt_sphere* spheres, size_t n_spheres);
 
+/* Build the acceleration structure ON THE DEVICE from an indexed triangle mesh — an EXTENSION
+ * (the reference builds on the host: SplitBVHBuilder.cpp, BasicScene.cpp:281-294).
+ * Linear BVH (Morton order, Karras hierarchy, bottom-up fit) collapsed into the same item
+ * buffer pt_upload_bvh produces, in milliseconds; no SAH, so the tree traces slower than the
+ * host builder's.  Rendered images are the same bit for bit (the closest hit does not depend
+ * on the tree).  Triangle ids are the row numbers of `tris`.  PT_OPT_LEAF_MAX (default 2)
+ * = triangles per leaf.  verts: float[n_verts][3], tris: int32[n_tris][3]; host arrays, copied. */
+int pt_build_bvh(pt_ctx* ctx, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris);
+int pt_last_build_ms(pt_ctx* ctx, float* ms_out);   /* device time of the last pt_build_bvh */
+
 /* Per-triangle materials — an EXTENSION.  The reference parses the .mtl into
  * `materials` but never reads it (utilfun.cpp:458-462) and shades every triangle with the ONE
  * material of kernelInfo (tracer.cu:131-135 = pt_params.tri_mat/tri_col/tri_emi/phong_expo).

@@ -1,0 +1,156 @@
+"""pt_build_bvh — the BVH built ON the device (extension; csrc/pt_build.h).
+
+The reference builds on the host and holds no fixture for a device builder; what pins this one
+is the path's own invariant: the closest hit (exact Moller-Trumbore, equal-t ties to the smaller
+triangle id) does not depend on the tree, so a device-built tree must give
+  * the brute-force oracle's (t, id) on explicit ray batches, bit for bit, and
+  * the oracle's image (rendered over the HOST builder's tree), bit for bit for the binary walks,
+    <= 2 grazing pixels for the quantised wide walks (the bar of test_gpu_wide.py)."""
+import numpy as np
+import pytest
+
+import gpu_pathtracer_amd as g
+import orc
+from test_gpu_parity import gpu_trace, golden_camera
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "mega-wide": (g.KERNEL_MEGA_BVH2, 2),
+            "persistent-unified": (g.KERNEL_PERSISTENT, 1), "mega-whilewhile": (g.KERNEL_MEGA_BVH2, 0)}
+
+
+@pytest.fixture(scope="module", params=list(VARIANTS), ids=list(VARIANTS))
+def pt(request):
+    t = g.PathTracer(0)
+    t.set_option(g.OPT_KERNEL, VARIANTS[request.param][0])
+    t.set_option(g.OPT_WALK, VARIANTS[request.param][1])
+    t.max_diff = 2 if VARIANTS[request.param][1] >= 2 else 0
+    yield t
+    t.close()
+
+
+def random_rays(mesh, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = mesh.bounds()
+    c, r = 0.5 * (lo + hi), 0.5 * np.linalg.norm(hi - lo)
+    o = c + rng.normal(size=(n, 3)) * r * 1.2
+    tgt = lo + rng.random((n, 3)) * (hi - lo)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3], rays[:, 4:7] = o, d
+    return rays
+
+
+@pytest.mark.parametrize("name", ["cornell", "bunny_low", "gto_sixteen", "dragon"])
+def test_device_tree_hits_equal_brute_force(name):
+    mesh = g.scene_mesh(name)
+    t = g.PathTracer(0)
+    try:
+        for leaf_max in (1, 2, 4):
+            t.set_option(g.OPT_LEAF_MAX, leaf_max)
+            ms = t.build_bvh(mesh)
+            info = t.scene_info()
+            print(f"{name} leaf_max {leaf_max}: built in {ms:.2f} ms on the device, {info}")
+            assert info["n_tri_refs"] == mesh.n_tris and info["n_inner"] == mesh.n_tris - 1
+            assert info["n_leaves"] >= mesh.n_tris / leaf_max and info["max_depth"] <= 64
+            n = 20000 if name == "dragon" else 60000
+            rays = random_rays(mesh, n, 7 + leaf_max)
+            for cull in (True, False):
+                tg, ig, ng = gpu_trace(t, rays, cull)
+                tb, ib, nb = orc.trace_brute(mesh, rays, cull)
+                assert np.array_equal(ig, ib)
+                assert np.array_equal(tg, tb)
+                hit = ib >= 0
+                assert hit.mean() > 0.2 and np.array_equal(ng[hit], nb[hit])
+    finally:
+        t.close()
+
+
+@pytest.mark.parametrize("scene,W,H,spp", [("cornell", 256, 256, 2), ("cornell_dragon", 640, 360, 2), ("gto_sixteen", 321, 175, 3)])
+def test_device_tree_image_equals_oracle(pt, scene, W, H, spp):
+    mesh = g.scene_mesh(scene)
+    host_bvh = g.Bvh(mesh)
+    sph = g.reference_spheres()
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.frame, p.flags = 4, g.FLAG_WRITE_RGBA
+    ref, rref, _ = orc.render(host_bvh, sph, cam, p, spp)
+    pt.upload_tri_materials(None, None)
+    ms = pt.build_bvh(mesh)
+    pt.upload_spheres(sph)
+    acc, rgba = pt.alloc_frame(W, H)
+    pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+    pt.sync()
+    a, r = acc.download(np.float32, (H, W, 3)), rgba.download(np.uint32, (H, W))
+    acc.free()
+    rgba.free()
+    n_diff = int(np.any(a != ref, axis=-1).sum())
+    print(f"{scene}: device build {ms:.2f} ms, differing pixels {n_diff} of {W * H}")
+    assert n_diff <= pt.max_diff
+    if n_diff == 0:
+        assert np.array_equal(r, rref)
+
+
+def test_degenerate_inputs():
+    t = g.PathTracer(0)
+    try:
+        # one triangle, two triangles, 300 copies of ONE triangle (all Morton keys equal: the
+        # position tie-break keeps the hierarchy a balanced tree; equal t -> smallest id)
+        v = np.array([[-1, -1, -5], [1, -1, -5], [0, 1, -5], [3, -1, -6], [5, -1, -6], [4, 1, -6]], np.float32)
+        rays = np.zeros((3, 8), np.float32)
+        rays[:, 4:7] = (0, 0, -1)
+        rays[1, :3] = (4, 0, 0)
+        rays[2, :3] = (9, 9, 0)
+        for tris, expect in (([[0, 1, 2]], [0, -1, -1]), ([[0, 1, 2], [3, 4, 5]], [0, 1, -1]),
+                             ([[0, 1, 2]] * 300 + [[3, 4, 5]] * 5, [0, 300, -1])):
+            m = g.Mesh.from_arrays(v, np.array(tris, np.int32))
+            for leaf_max in (1, 2, 8):
+                t.set_option(g.OPT_LEAF_MAX, leaf_max)
+                t.build_bvh(m)
+                tg, ig, _ = gpu_trace(t, rays, False)
+                assert ig.tolist() == expect
+                assert tg[0] == 5.0
+        # errors: index out of range, NaN vertex, empty mesh
+        lib = t._lib
+        bad = np.array([[0, 1, 7]], np.int32)
+        assert lib.pt_build_bvh(t._ctx, v.ctypes.data, 6, bad.ctypes.data, 1) != 0
+        vn = v.copy()
+        vn[2, 1] = np.nan
+        ok = np.array([[0, 1, 2]], np.int32)
+        assert lib.pt_build_bvh(t._ctx, vn.ctypes.data, 6, ok.ctypes.data, 1) != 0
+        assert lib.pt_build_bvh(t._ctx, v.ctypes.data, 6, ok.ctypes.data, 0) != 0
+        # ... and the context still works afterwards
+        t.build_bvh(g.Mesh.from_arrays(v, ok))
+        assert gpu_trace(t, rays, False)[1].tolist() == [0, -1, -1]
+    finally:
+        t.close()
+
+
+def test_device_build_800k_speed_and_parity():
+    """The bench scene: build time, and the 1080p frame against the host-tree render of the same kernel."""
+    mesh = g.scene_mesh("cornell_dragon_800k")
+    W, H = 1920, 1080
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    sph = g.reference_spheres()
+    t = g.PathTracer(0)
+    try:
+        def frame():
+            t.upload_spheres(sph)
+            acc, rgba = t.alloc_frame(W, H)
+            t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 1)
+            t.sync()
+            a = acc.download(np.float32, (H, W, 3))
+            acc.free()
+            rgba.free()
+            return a
+        t.upload_bvh(g.Bvh(mesh))
+        a_host = frame()
+        ms = min(t.build_bvh(mesh) for _ in range(3))
+        info = t.scene_info()
+        a_dev = frame()
+        n_diff = int(np.any(a_host != a_dev, axis=-1).sum())
+        print(f"800k: device build {ms:.1f} ms, {info}; differing pixels vs host tree {n_diff}")
+        assert ms < 200.0
+        assert n_diff <= 40
+    finally:
+        t.close()
