@@ -621,18 +621,28 @@ struct PathState {
     pt_rng rng;
 };
 
+// The kernel-argument block seen through an opaque pointer (constant address space, scalar loads):
+// a field read as K.x is fetched at that point instead of being preloaded and kept in SGPRs for
+// the whole kernel.  KParams is the one and only argument of every kernel that uses this: offset 0.
+#define PT_KARGS(K)                                                                               \
+    const __attribute__((address_space(4))) KParams* K##_p =                                      \
+        (const __attribute__((address_space(4))) KParams*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(K##_p));                                                               \
+    const __attribute__((address_space(4))) KParams& K = *K##_p
+
 // RNG seed (tracer.cu:362-363) + getCamRayDir, cudaUtils.h:111-134 (origin ON the image plane)
 __device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uint64_t pix, uint64_t frame, PathState& ps) {
+    PT_KARGS(K);   // camera: read where it is used, not held in SGPRs across the persistent loop
     ps.rng = pt_rng_init(pt_wang64(frame), pix);
     const float u0 = pt_rng_next(ps.rng), u1 = pt_rng_next(ps.rng);
     const float jx = u0 - 0.5f, jy = u1 - 0.5f;
-    const float xs = ((((float)px - (float)P.W / 2.0f) + 0.5f) + jx) * P.cam.dist * P.cam.aspect * P.cam.fov / (float)(P.W - 1);
-    const float ys = ((((float)py - (float)P.H / 2.0f) + 0.5f) + jy) * P.cam.dist * P.cam.fov / (float)(P.H - 1);
-    const v3 front = V3(P.cam.front[0], P.cam.front[1], P.cam.front[2]);
-    const v3 right = V3(P.cam.right[0], P.cam.right[1], P.cam.right[2]);
-    const v3 up = V3(P.cam.up[0], P.cam.up[1], P.cam.up[2]);
-    const v3 dir0 = vmadd(up, ys, vmadd(right, xs, vscale(front, P.cam.dist)));
-    ps.o = vadd(V3(P.cam.pos[0], P.cam.pos[1], P.cam.pos[2]), dir0);
+    const float xs = ((((float)px - (float)P.W / 2.0f) + 0.5f) + jx) * K.cam.dist * K.cam.aspect * K.cam.fov / (float)(P.W - 1);
+    const float ys = ((((float)py - (float)P.H / 2.0f) + 0.5f) + jy) * K.cam.dist * K.cam.fov / (float)(P.H - 1);
+    const v3 front = V3(K.cam.front[0], K.cam.front[1], K.cam.front[2]);
+    const v3 right = V3(K.cam.right[0], K.cam.right[1], K.cam.right[2]);
+    const v3 up = V3(K.cam.up[0], K.cam.up[1], K.cam.up[2]);
+    const v3 dir0 = vmadd(up, ys, vmadd(right, xs, vscale(front, K.cam.dist)));
+    ps.o = vadd(V3(K.cam.pos[0], K.cam.pos[1], K.cam.pos[2]), dir0);
     ps.d = vnormalize(dir0);
     ps.mask = V3(1.f, 1.f, 1.f);
     ps.accu = V3(0.f, 0.f, 0.f);
@@ -642,6 +652,7 @@ __device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uin
 // One bounce after the closest triangle hit `h` is known (tracer.cu:98-296).  Returns true
 // when the sample is complete (col_out valid), false when ps holds the next ray segment.
 __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out) {
+    PT_KARGS(K);   // shading scalars: read where they are used (see the sphere loop)
     const v3 o = ps.o, d = ps.d;
     v3 mask = ps.mask, accu = ps.accu;
     pt_rng rng = ps.rng;
@@ -656,10 +667,18 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     // the divergent service phase hipcc otherwise keeps the loop counter in a VGPR and fetches each
     // sphere with dependent vector loads (a quarter of the kernel's vector-memory instructions).
     if (P.sc.n_spheres <= PT_KSPHERES) {
+        // The centres/radii ride in the kernel-argument block, but are re-read HERE, one scalar load
+        // per sphere behind an opaque pointer: kept in SGPRs across the whole persistent loop they
+        // push ~50 other scalars into spill lanes (v_readlane/v_writelane on the hot path; measured
+        // -4 % frame time, and what lets 6 waves per SIMD pay off).  A plain global pointer makes
+        // hipcc fetch them with per-lane vector loads instead (+2 %).
+        // KParams is the one and only kernel argument of every kernel that shades: offset 0.
+        typedef const __attribute__((address_space(4))) float kfloat;
+        kfloat* kp = (kfloat*)&K.ksph[0];
 #pragma unroll
         for (int i = 0; i < PT_KSPHERES; i++) {
             if (i < P.sc.n_spheres) {
-                const pt_sphere_d& s = P.ksph[i];
+                struct { float px, py, pz, rad; } s = {kp[11 * i], kp[11 * i + 1], kp[11 * i + 2], kp[11 * i + 3]};
                 const float ts = pt_sphere_intersect(s.px, s.py, s.pz, s.rad, o, d);
                 if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
             }
@@ -674,7 +693,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     v3 hitpos = vmadd(d, scene_t, o);
     v3 n, nl, objcol, emit;
     int mat;
-    float phong = P.phong;
+    float phong = K.phong;
     if (geom == 1) {
         const pt_sphere_d& s = P.sc.spheres[sph_id];
         n = vnormalize(vsub(hitpos, V3(s.px, s.py, s.pz)));
@@ -685,26 +704,26 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     } else if (geom == 0) {
         n = vnormalize(h.n);
         nl = n;  // tracer.cu:126-127
-        if ((P.flags & PT_FLAG_FACE_FORWARD) && !(vdot(n, d) < 0)) nl = vscale(n, -1.0f);
-        if (P.tri_matid) {  // extension: per-triangle material row
-            const int row = P.tri_matid[h.tri];
-            const float4 m0 = P.mat_table[2 * row], m1 = P.mat_table[2 * row + 1];
+        if ((K.flags & PT_FLAG_FACE_FORWARD) && !(vdot(n, d) < 0)) nl = vscale(n, -1.0f);
+        if (K.tri_matid) {  // extension: per-triangle material row
+            const int row = K.tri_matid[h.tri];
+            const float4 m0 = K.mat_table[2 * row], m1 = K.mat_table[2 * row + 1];
             objcol = V3(m0.x, m0.y, m0.z);
             emit = V3(m0.w, m1.x, m1.y);
             mat = __float_as_int(m1.z);
             phong = m1.w;
         } else {
-            objcol = V3(P.tri_col[0], P.tri_col[1], P.tri_col[2]);
-            emit = V3(P.tri_emi[0], P.tri_emi[1], P.tri_emi[2]);
-            mat = P.tri_mat;
+            objcol = V3(K.tri_col[0], K.tri_col[1], K.tri_col[2]);
+            emit = V3(K.tri_emi[0], K.tri_emi[1], K.tri_emi[2]);
+            mat = K.tri_mat;
         }
     } else {
-        col_out = V3(P.bk[0], P.bk[1], P.bk[2]);  // tracer.cu:140-142: unmasked background
+        col_out = V3(K.bk[0], K.bk[1], K.bk[2]);  // tracer.cu:140-142: unmasked background
         return true;
     }
     accu = vadd(accu, vmul(mask, emit));
 
-    if ((P.flags & PT_FLAG_RUSSIAN_ROULETTE) && ps.depth >= 2) {  // extension
+    if ((K.flags & PT_FLAG_RUSSIAN_ROULETTE) && ps.depth >= 2) {  // extension
         const float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
         if (!(pt_rng_next(rng) < pr)) { col_out = accu; return true; }
         objcol = vscale(objcol, 1.0f / pr);
@@ -712,7 +731,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
 
     v3 nextdir;
     if (mat == PT_MAT_DIFF) {  // tracer.cu:156-186
-        if (!(P.flags & PT_FLAG_COSINE_DIFF)) {
+        if (!(K.flags & PT_FLAG_COSINE_DIFF)) {
             (void)pt_rng_next(rng);
             (void)pt_rng_next(rng);
         }
@@ -723,7 +742,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         float c, s;
         pt_sincos2pi(f1, c, s);
         v3 rv;
-        if (P.flags & PT_FLAG_COSINE_DIFF) {  // extension: pdf = cos/pi
+        if (K.flags & PT_FLAG_COSINE_DIFF) {  // extension: pdf = cos/pi
             const float r2s = sqrtf(f2);
             rv = V3(c * r2s, sqrtf(1.0f - f2), s * r2s);
         } else {
@@ -738,7 +757,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         mask = vmul(mask, objcol);
     } else if (mat == PT_MAT_REFR) {  // :205-256
         const bool into = vdot(n, nl) > 0;
-        const float nc = P.air_ior, ntt = P.glass_ior;
+        const float nc = K.air_ior, ntt = K.glass_ior;
         const float nnt = into ? nc / ntt : ntt / nc;
         const float ddn = vdot(d, nl);
         const float cos2t = 1.0f - nnt * nnt * (1.0f - ddn * ddn);
@@ -748,7 +767,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         } else {
             const float k = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
             const v3 tdir = vnormalize(vmadd(n, -k, vscale(d, nnt)));
-            const bool fix = (P.flags & PT_FLAG_GLASS_FIX) != 0;  // extension
+            const bool fix = (K.flags & PT_FLAG_GLASS_FIX) != 0;  // extension
             const float R0 = fix ? ((ntt - nc) * (ntt - nc)) / ((ntt + nc) * (ntt + nc))
                                  : (ntt - nc) * (ntt - nc) / (ntt + nc) * (ntt + nc);  // sic, :230
             const float c = 1.0f - (into ? -ddn : vdot(tdir, n));
@@ -778,7 +797,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         const v3 uu = vnormalize(vcross(ax, w1));
         const v3 vv = vcross(w1, uu);
         const v3 base = vmadd(vv, sphi * sinT, vscale(uu, cphi * sinT));
-        if (P.flags & PT_FLAG_METAL_LITERAL_W) {
+        if (K.flags & PT_FLAG_METAL_LITERAL_W) {
             const float wc = (float)P.W * cosT;  // tracer.cu:280
             nextdir = V3(base.x + wc, base.y + wc, base.z + wc);
         } else {

@@ -73,13 +73,13 @@ struct pt_ctx {
     float* d_samples = nullptr;        // [spp][H*W][3] sample colours of a multi-sample call
     size_t samples_bytes = 0;
     int n_cu = 0;
-    int opt_batch = 36;
+    int opt_batch = 40;
     int opt_vote_node = 1, opt_vote_rec = 1;
-    int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
+    int opt_refill = 12;         // idle lanes that trigger a refill (PT_OPT_REFILL)
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
-    int opt_occ = 5;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
+    int opt_occ = 8;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
-    int opt_walk = 4;            // 0 while-while, 1 unified-step, 2 wide, 4 wide + postponed leaf (PT_OPT_WALK)
+    int opt_walk = 2;            // 0 while-while, 1 unified-step, 2 wide, 4 wide + postponed leaf (PT_OPT_WALK)
     int opt_leaf_max = 2;        // leaves with more references are split at upload (PT_OPT_LEAF_MAX)
     int opt_tri_test = 0;        // 0 Moller-Trumbore records, 1 Woop records (next upload; PT_OPT_TRI_TEST)
     bool records_woop = false;   // what the uploaded records are

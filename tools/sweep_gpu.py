@@ -18,6 +18,7 @@ ap.add_argument("--spp", type=int, default=1)
 ap.add_argument("--no-spheres", action="store_true")
 ap.add_argument("--bvh", default="", help="builder overrides, e.g. split_alpha=1e-5,sah_tri_cost=2")
 ap.add_argument("--leaf-max", type=int, default=2)
+ap.add_argument("--device-build", action="store_true", help="pt_build_bvh (LBVH on the device) instead of the host SAH/SBVH tree")
 ap.add_argument("--variants", default="mega::64:8:16:0,mega::0:8:16:1,mega::0:6:16:1,mega::0:4:16:1,persist:16:0:8:16:1,persist:16:0:6:16:1,persist:16:0:4:16:1,persist:8:0:8:16:1,persist:32:0:8:16:1,persist:16:64:8:16:0",
                 help="comma list of kernel[:batch[:top_nodes[:occupancy[:lds_stack[:walk[:refill[:vote_node[:vote_rec]]]]]]]]")
 a = ap.parse_args()
@@ -27,11 +28,14 @@ kw = {}
 for item in filter(None, a.bvh.split(",")):
     k, v = item.split("=")
     kw[k] = float(v) if k in ("split_alpha", "sah_tri_cost", "sah_node_cost") else int(v)
-bvh = g.Bvh(g.scene_mesh(a.scene), **kw)
-print("bvh", kw, bvh.stats)
 pt = g.PathTracer(0)
 pt.set_option(g.OPT_LEAF_MAX, a.leaf_max)
-pt.upload_bvh(bvh)
+if a.device_build:
+    print("device build ms", pt.build_bvh(g.scene_mesh(a.scene)))
+else:
+    bvh = g.Bvh(g.scene_mesh(a.scene), **kw)
+    print("bvh", kw, bvh.stats)
+    pt.upload_bvh(bvh)
 print("leaf_max", a.leaf_max, pt.scene_info())
 pt.upload_spheres(None if a.no_spheres else g.reference_spheres())
 cam = g.default_camera(W, H)
