@@ -72,8 +72,16 @@ struct KParams {
 struct Hit {
     float t;   // PT_F32_MAX on miss
     int tri;   // original triangle id, -1 on miss
-    v3 n;      // cross(v0-v1, v0-v2) of the winner
+    int rec;   // float4 index of the winner's record: its 4th piece holds cross(v0-v1, v0-v2),
+               // fetched once per segment by pt_hit_normal instead of at every improvement (and two
+               // registers less to carry through the walk)
 };
+
+// the un-normalised geometric normal of a hit triangle (4th piece of its record)
+__device__ __forceinline__ v3 pt_hit_normal(const KScene& sc, const Hit& h) {
+    const float4 q3 = sc.nodes[h.rec + 3];
+    return V3(q3.x, q3.y, q3.z);
+}
 
 struct TravCount {
     uint32_t inner, tris, leaves;
@@ -163,7 +171,7 @@ __device__ __forceinline__ void trav_begin(TravState& s, v3 o, v3 d, STK& stk, i
     s.sp = 0;
     stk.put(0, PT_SENTINEL);
     s.leaf = 0; s.node = root;
-    s.h.t = PT_F32_MAX; s.h.tri = -1; s.h.n = V3(0.f, 0.f, 0.f);
+    s.h.t = PT_F32_MAX; s.h.tri = -1; s.h.rec = 0;
 }
 
 // returns true when the walk is complete
@@ -241,8 +249,7 @@ __device__ __forceinline__ bool trav_run(TravState& s, const KScene& sc, v3 o, v
                 if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                     h.t = t;
                     h.tri = id;
-                    const float4 r3 = sc.tris[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
-                    h.n = V3(r3.x, r3.y, r3.z);
+                    h.rec = a;
                 }
                 if (__float_as_int(r1.w) != 0) break;  // last record of the leaf
             }
@@ -326,8 +333,7 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
             if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                 h.t = t;
                 h.tri = id;
-                const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
-                h.n = V3(q3.x, q3.y, q3.z);
+                h.rec = a;
             }
             if (__float_as_int(q1.w) != 0) {  // last record of the leaf
                 cur = stk.get(sp);
@@ -469,12 +475,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                 h.t = t;
                 h.tri = id;
-                if (WOOP) {
-                    h.n = V3(qw.x, qw.y, qw.z);
-                } else {
-                    const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
-                    h.n = V3(q3.x, q3.y, q3.z);
-                }
+                h.rec = a;
             }
             if (last) {  // last record of the leaf
                 cur = stk.get(sp);
@@ -577,8 +578,7 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
             if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
                 h.t = t;
                 h.tri = id;
-                const float4 q3 = sc.nodes[a + 3];  // cross(v0-v1, v0-v2), hoisted to upload
-                h.n = V3(q3.x, q3.y, q3.z);
+                h.rec = a;
             }
             if (__float_as_int(q1.w) != 0) {  // last record of the leaf
                 pend = 0;
@@ -702,7 +702,7 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
         emit = V3(s.emi[0], s.emi[1], s.emi[2]);
         mat = s.mat;
     } else if (geom == 0) {
-        n = vnormalize(h.n);
+        n = vnormalize(pt_hit_normal(P.sc, h));
         nl = n;  // tracer.cu:126-127
         if ((K.flags & PT_FLAG_FACE_FORWARD) && !(vdot(n, d) < 0)) nl = vscale(n, -1.0f);
         if (K.tri_matid) {  // extension: per-triangle material row
@@ -844,7 +844,7 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
     if (P.depth == 0) return col;
     for (;;) {
         Hit h;
-        h.t = PT_F32_MAX; h.tri = -1; h.n = V3(0.f, 0.f, 0.f);
+        h.t = PT_F32_MAX; h.tri = -1; h.rec = 0;
         if (P.sc.has_bvh) {
             if (ALG >= 2) {
                 TravState ts;
@@ -963,7 +963,10 @@ __global__ void __launch_bounds__(PT_BLOCK_RAYS) k_trace_rays_bvh2(const KScene 
     const Hit h = trav_bvh2<false, true>(sc, V3(ro.x, ro.y, ro.z), V3(rd.x, rd.y, rd.z), cull != 0, stk, tc, s_top);
     t_out[i] = h.t;
     tri_out[i] = h.tri;
-    if (n_out) { n_out[3 * i] = h.n.x; n_out[3 * i + 1] = h.n.y; n_out[3 * i + 2] = h.n.z; }
+    if (n_out) {
+        const v3 hn = h.tri != -1 ? pt_hit_normal(sc, h) : V3(0.f, 0.f, 0.f);
+        n_out[3 * i] = hn.x; n_out[3 * i + 1] = hn.y; n_out[3 * i + 2] = hn.z;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1004,15 +1007,13 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
 
     int phase = PH_IDLE;
     uint32_t pix = 0, s_idx = 0;
-    int px = 0, py = 0;
-    float ax = 0.f, ay = 0.f, az = 0.f;
     PathState ps;
     TravState ts;
     ps.o = ps.d = ps.mask = ps.accu = V3(0.f, 0.f, 0.f);
     ps.depth = 0; ps.rng.s0 = ps.rng.s1 = ps.rng.n = 0;
     ts.idx = ts.idy = ts.idz = ts.oodx = ts.oody = ts.oodz = 0.f;
     ts.node = PT_SENTINEL; ts.leaf = 0; ts.sp = 0;
-    ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.n = V3(0.f, 0.f, 0.f);
+    ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.rec = 0;
 
     TravCount tc;
     tc.inner = tc.tris = tc.leaves = 0;
@@ -1052,6 +1053,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t take = min((uint32_t)n_idle, avail);
+            bool started = false;
             if (phase == PH_IDLE) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (rank < take) {
@@ -1063,42 +1065,32 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                     }
                     int tx, ty;
                     if (pt_tile_coords(P, (int)(q >> 6), tx, ty)) {
-                        px = tx * PT_TILE + (int)(q & 7u);
-                        py = ty * PT_TILE + (int)((q >> 3) & 7u);
+                        const int px = tx * PT_TILE + (int)(q & 7u);
+                        const int py = ty * PT_TILE + (int)((q >> 3) & 7u);
                         if (px < P.W && py < P.H) {  // tracer.cu:358
                             pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
                             s_idx = s_first;
-                            ax = ay = az = 0.f;
-                            if (!P.samples && P.sample_index != 1) {
-                                const float* acc = P.accum + 3 * (size_t)pix;
-                                ax = acc[0]; ay = acc[1]; az = acc[2];
+                            // camera ray, then walk (or straight to shading); px/py live only here
+                            path_begin(P, px, py, (uint64_t)pix, P.frame + s_idx, ps);
+                            if (P.depth == 0) {
+                                phase = PH_SHADE;
+                                ts.h.t = PT_F32_MAX; ts.h.tri = -1;
+                            } else if (P.sc.has_bvh) {
+                                trav_begin(ts, ps.o, ps.d, stk, ALG >= 2 ? P.sc.wide_root : 0);
+                                phase = PH_TRAV;
+                            } else {
+                                ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.rec = 0;
+                                phase = PH_SHADE;
                             }
-                            phase = PH_SHADE;  // "needs a new sample": handled at the top of C
-                            ps.depth = 0xffffffffu;
+                            started = true;
                         }
                     }
                 }
             }
             chunk_next += take;
-        }
-
-        // ---- C0. lanes that start a sample: camera ray, then walk (or straight to shading)
-        if (COUNT) {
-            const int nb = __popcll(__ballot(phase == PH_SHADE && ps.depth == 0xffffffffu));
-            if (nb) { it_begin++; act_begin += nb; }
-        }
-        if (phase == PH_SHADE && ps.depth == 0xffffffffu) {
-            path_begin(P, px, py, (uint64_t)pix, P.frame + s_idx, ps);
-            if (P.depth == 0) {
-                ps.depth = 0;
-                phase = PH_SHADE;
-                ts.h.t = PT_F32_MAX; ts.h.tri = -1;
-            } else if (P.sc.has_bvh) {
-                trav_begin(ts, ps.o, ps.d, stk, ALG >= 2 ? P.sc.wide_root : 0);
-                phase = PH_TRAV;
-            } else {
-                ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.n = V3(0.f, 0.f, 0.f);
-                phase = PH_SHADE;
+            if (COUNT) {
+                const int nb = __popcll(__ballot(started));
+                if (nb) { it_begin++; act_begin += nb; }
             }
         }
 
@@ -1116,10 +1108,10 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
 
         // ---- C. shade finished segments
         if (COUNT) {
-            const int nb = __popcll(__ballot(phase == PH_SHADE && ps.depth != 0xffffffffu));
+            const int nb = __popcll(__ballot(phase == PH_SHADE));
             if (nb) { it_shade++; act_shade += nb; }
         }
-        if (phase == PH_SHADE && ps.depth != 0xffffffffu) {
+        if (phase == PH_SHADE) {
             v3 col = V3(0.f, 0.f, 0.f);
             bool done;
             if (P.depth == 0) {
@@ -1139,17 +1131,16 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                 if (COUNT) n_paths++;
                 phase = PH_IDLE;
             } else {
-                pt_accumulate(ax, ay, az, col, P.sample_index + s_idx);
+                // one sample per call (spp > 1 always comes with the sample buffer): fold it straight
+                // into the accumulator; nothing of the pixel's running mean is carried through the walk
+                float* acc = P.accum + 3 * (size_t)pix;
+                float ax = 0.f, ay = 0.f, az = 0.f;
+                if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
+                pt_accumulate(ax, ay, az, col, P.sample_index);
                 if (COUNT) n_paths++;
-                s_idx++;
-                if (s_idx < P.spp) {
-                    ps.depth = 0xffffffffu;  // next sample of the same pixel
-                } else {
-                    float* acc = P.accum + 3 * (size_t)pix;
-                    acc[0] = ax; acc[1] = ay; acc[2] = az;
-                    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
-                    phase = PH_IDLE;
-                }
+                acc[0] = ax; acc[1] = ay; acc[2] = az;
+                if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
+                phase = PH_IDLE;
             }
         }
 

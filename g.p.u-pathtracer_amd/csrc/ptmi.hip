@@ -73,9 +73,9 @@ struct pt_ctx {
     float* d_samples = nullptr;        // [spp][H*W][3] sample colours of a multi-sample call
     size_t samples_bytes = 0;
     int n_cu = 0;
-    int opt_batch = 40;
+    int opt_batch = 36;
     int opt_vote_node = 1, opt_vote_rec = 1;
-    int opt_refill = 12;         // idle lanes that trigger a refill (PT_OPT_REFILL)
+    int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
     int opt_occ = 8;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)

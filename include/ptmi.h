@@ -90,7 +90,7 @@ enum {
     PT_OPT_COUNTERS = 2,      /* 1 = instrumented launch: fill pt_counters (slower)         */
     PT_OPT_TIMING = 3,        /* 1 = bracket every launch with hipEvents (pt_last_kernel_ms) */
     PT_OPT_BATCH = 4,         /* persistent kernel: waiting lanes (1..64) that make a wave
-                                 leave the traversal loop to shade / refill; default 40      */
+                                 leave the traversal loop to shade / refill; default 36      */
     PT_OPT_TOP_NODES = 5,     /* BVH nodes (breadth-first prefix, 0..1024) mirrored in LDS    */
     PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the registers are budgeted for: 4/5/6/8 (default 8) */
     PT_OPT_LDS_STACK = 7,     /* traversal-stack entries kept in LDS per lane: 16 (default) or
@@ -103,7 +103,7 @@ enum {
                                  per cent faster at 5 waves/SIMD, level at 8; all report the
                                  same hits                                                      */
     PT_OPT_REFILL = 11,       /* persistent kernel: idle lanes (1..64) that trigger a refill from the
-                                 work queue; default 12; values above PT_OPT_BATCH are
+                                 work queue; default 8; values above PT_OPT_BATCH are
                                  clamped to it (a wave must always have work to go to)          */
     PT_OPT_VOTE_NODE = 12,    /* walk 4: a wave runs a node step when                              */
     PT_OPT_VOTE_REC = 13,     /*   lanes_with_node * VOTE_NODE >= lanes_with_record * VOTE_REC (1, 1) */
