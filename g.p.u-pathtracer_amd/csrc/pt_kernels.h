@@ -413,6 +413,15 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         }
         if (cur >= 0) {
             if (COUNT) tc.inner++;
+#ifdef PT_EXP_LOAD   // sensitivity experiment: one more 16-byte access to the node's line per node step
+            { const float4 dummy = sc.nodes[a + 3]; asm volatile("" :: "v"(dummy.x), "v"(dummy.w)); }
+#endif
+#ifdef PT_EXP_VALU   // sensitivity experiment: 32 more dependent VALU instructions per node step
+            { float z = q0.x;
+#pragma unroll
+              for (int e = 0; e < 32; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(z));
+              asm volatile("" :: "v"(z)); }
+#endif
             const uint32_t meta = __float_as_uint(q0.w);
             const float sx = __uint_as_float((meta & 0xffu) << 23) * idx;
             const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy;
