@@ -486,6 +486,25 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
                 h.tri = id;
                 h.rec = a;
             }
+            // finish the leaf inside THIS iteration: its next record sits in the same or the next cache
+            // line, so the extra fetch is short, and the wave saves a vote + a phase switch per record
+            // (-1.4 % at 8 waves/SIMD, -3 % at 5-6)
+            if (!WOOP) {
+                int aa = a;
+                while (!last) {
+                    aa += 4;
+                    const float4 r0 = sc.nodes[aa], r1 = sc.nodes[aa + 1], r2 = sc.nodes[aa + 2];
+                    if (COUNT) tc.tris++;
+                    const float t2 = pt_mt_intersect(V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), V3(r2.x, r2.y, r2.z), o, d, cull);
+                    const int id2 = __float_as_int(r0.w);
+                    last = __float_as_int(r1.w) != 0;
+                    if (t2 > 0.0f && (t2 < h.t || (t2 == h.t && h.tri != -1 && id2 < h.tri))) {
+                        h.t = t2;
+                        h.tri = id2;
+                        h.rec = aa;
+                    }
+                }
+            }
             if (last) {  // last record of the leaf
                 cur = stk.get(sp);
                 sp--;
