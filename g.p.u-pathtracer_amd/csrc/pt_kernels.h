@@ -457,7 +457,11 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
 #define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
             if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
             if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
-            if (key[1] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[1])); }
+            if (key[1] != 0xffffffffu) {
+                const int lk = PT_LINK(key[1]);
+                sp++;
+                stk.put(sp, lk);
+            }
             if (key[0] != 0xffffffffu) {
                 cur = PT_LINK(key[0]);
             } else {
