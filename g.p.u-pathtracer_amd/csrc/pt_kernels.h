@@ -118,9 +118,7 @@ struct TravState {
 // mix of depths is conflict-free); deeper entries — rare: the walk pushes one entry per level
 // that has both children hit — overflow into a private (scratch) array.  A small LSTK is what
 // lets 6-8 waves per SIMD fit in the CU's 160 KiB of LDS (64 B/lane at LSTK = 16).
-// lane id recomputed where it is used (2 VALU): kept in a register across the walk it is the
-// first thing hipcc spills at 64-80 VGPRs, and a scratch reload in front of every push/pop
-// puts a vector-memory round trip on the loop's critical path
+// lane id of the calling lane (v_mbcnt), opaque to the optimiser
 __device__ __forceinline__ int pt_lane_fresh() {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
@@ -140,10 +138,13 @@ struct TravStack {
     // the overflow array is a SEPARATE private object: as a member it drags the whole struct,
     // `base` included, into scratch memory (a scratch reload in front of every push)
     int (&ovf)[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
-    __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK>& o) : base(b), ovf(o.e) {}
+    int lane_base;  // base + lane id.  Re-deriving the lane id at every access (v_mbcnt x2 + add) was the
+                    // cheaper choice while ~120 SGPR spills ate the VGPR budget; with the kernel arguments
+                    // read at use, one VGPR here saves ~12 VALU per node step (-1.4 % / -3.3 % at 8 / 6 waves)
+    __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK>& o) : base(b), ovf(o.e), lane_base(b + pt_lane_fresh()) {}
     __device__ __forceinline__ void put(int sp, int v) {
         if (LSTK >= PT_STACK_CAP || sp < LSTK) {
-            ((int*)s_dyn)[base + sp * BLOCK + pt_lane_fresh()] = v;
+            ((int*)s_dyn)[lane_base + sp * BLOCK] = v;
         } else {
             asm volatile("" : "+v"(v));
             ovf[sp - LSTK] = v;
@@ -152,7 +153,7 @@ struct TravStack {
     __device__ __forceinline__ int get(int sp) const {
         int v;
         if (LSTK >= PT_STACK_CAP || sp < LSTK) {
-            v = ((const int*)s_dyn)[base + sp * BLOCK + pt_lane_fresh()];
+            v = ((const int*)s_dyn)[lane_base + sp * BLOCK];
         } else {
             v = ovf[sp - LSTK];
             asm volatile("" : "+v"(v));

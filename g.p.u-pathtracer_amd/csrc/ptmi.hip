@@ -77,7 +77,7 @@ struct pt_ctx {
     int opt_vote_node = 1, opt_vote_rec = 1;
     int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
-    int opt_occ = 8;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
+    int opt_occ = 6;             // waves per SIMD the kernel is compiled for (PT_OPT_OCCUPANCY)
     int opt_lstk = 16;           // LDS stack entries per lane (deeper entries overflow to scratch)
     int opt_walk = 2;            // 0 while-while, 1 unified-step, 2 wide, 4 wide + postponed leaf (PT_OPT_WALK)
     int opt_leaf_max = 2;        // leaves with more references are split at upload (PT_OPT_LEAF_MAX)

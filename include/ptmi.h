@@ -92,7 +92,7 @@ enum {
     PT_OPT_BATCH = 4,         /* persistent kernel: waiting lanes (1..64) that make a wave
                                  leave the traversal loop to shade / refill; default 36      */
     PT_OPT_TOP_NODES = 5,     /* BVH nodes (breadth-first prefix, 0..1024) mirrored in LDS    */
-    PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the registers are budgeted for: 4/5/6/8 (default 8) */
+    PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the registers are budgeted for: 4/5/6/8 (default 6) */
     PT_OPT_LDS_STACK = 7,     /* traversal-stack entries kept in LDS per lane: 16 (default) or
                                  0 = all 72; deeper entries overflow to private memory        */
     PT_OPT_WALK = 8,          /* closest-hit walk: 0 = while-while (Aila-Laine order, as the
