@@ -24,9 +24,13 @@ __host__ __device__ inline void pt_encode_record(const float* v0, const float* v
 // 4-wide node: origin = the children's common lower corner, one power-of-two scale per axis,
 // child planes as bytes rounded OUTWARD (checked with the walk's own fma(q, scale, origin)), so a
 // decoded child box always contains the exact one:
-//   d[0..2] origin   d[3] = ex | ey<<8 | ez<<16 | n<<24 (biased exponents of the scales)
+//   d[0..2] origin   d[3], d[14], d[15] = the scales of x, y, z as floats (2^e: the walk multiplies
+//   them by 1/dir without decoding anything)
 //   d[4..6] lo bytes of x, y, z (child k in byte k)   d[7], d[8], d[9] hi bytes of x, y, z
-//   d[10..13] links of children 0..3                  d[14], d[15] unused
+//   d[10..13] links of children 0..3
+// A node with fewer than four children fills the unused slots with an INVERTED box (lo 255, hi 0:
+// entry > exit on every axis, never hit) and a copy of child 0's link, so the walk needs no child
+// count: should rounding ever let such a slot through, it only repeats work on child 0.
 __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, const int32_t* link, float* d) {
     PtBox nb = cb[0];
     for (int k = 1; k < n; k++)
@@ -35,7 +39,7 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
             nb.hi[a] = cb[k].hi[a] > nb.hi[a] ? cb[k].hi[a] : nb.hi[a];
         }
     uint32_t q[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t meta = (uint32_t)n << 24;
+    float scales[3];
     for (int a = 0; a < 3; a++) {
         const float origin = nb.lo[a];
         const float ext = nb.hi[a] - nb.lo[a];
@@ -48,7 +52,7 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
         e = e > 254 ? 254 : (e < 1 ? 1 : e);
         while (e < 254 && fmaf(255.f, pt_i2f(e << 23), origin) < nb.hi[a]) e++;
         const float scale = pt_i2f(e << 23);
-        meta |= (uint32_t)e << (8 * a);
+        scales[a] = scale;
         for (int k = 0; k < 4; k++) {
             int qlo = 255, qhi = 0;
             if (k < n) {
@@ -65,10 +69,10 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
             q[3 + a] |= (uint32_t)qhi << (8 * k);
         }
     }
-    d[0] = nb.lo[0]; d[1] = nb.lo[1]; d[2] = nb.lo[2]; d[3] = pt_i2f((int32_t)meta);
+    d[0] = nb.lo[0]; d[1] = nb.lo[1]; d[2] = nb.lo[2]; d[3] = scales[0];
     d[4] = pt_i2f((int32_t)q[0]); d[5] = pt_i2f((int32_t)q[1]); d[6] = pt_i2f((int32_t)q[2]); d[7] = pt_i2f((int32_t)q[3]);
     d[8] = pt_i2f((int32_t)q[4]); d[9] = pt_i2f((int32_t)q[5]);
-    d[10] = pt_i2f(n > 0 ? link[0] : 0); d[11] = pt_i2f(n > 1 ? link[1] : 0);
-    d[12] = pt_i2f(n > 2 ? link[2] : 0); d[13] = pt_i2f(n > 3 ? link[3] : 0);
-    d[14] = 0.f; d[15] = 0.f;
+    d[10] = pt_i2f(link[0]); d[11] = pt_i2f(n > 1 ? link[1] : link[0]);
+    d[12] = pt_i2f(n > 2 ? link[2] : link[0]); d[13] = pt_i2f(n > 3 ? link[3] : link[0]);
+    d[14] = scales[1]; d[15] = scales[2];
 }

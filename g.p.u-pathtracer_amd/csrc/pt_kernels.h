@@ -390,6 +390,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         float4 q0, q1, q2;
         float4 qw = make_float4(0.f, 0.f, 0.f, 0.f);  // WOOP: a record's 4th piece (normal | id<<1|last)
         int l2 = 0, l3 = 0;
+        float sc_y = 0.f, sc_z = 0.f;
         const int ti = a - sc.top_base;
         if (TOP && cur >= 0 && (unsigned)ti < (unsigned)(sc.n_top * 4)) {
             const int i = ti >> 2;
@@ -399,6 +400,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             const float4 q3 = s_dyn[3 * sc.n_top + i];
             l2 = __float_as_int(q3.x);
             l3 = __float_as_int(q3.y);
+            sc_y = q3.z; sc_z = q3.w;
             asm volatile("" : "+v"(q0.x), "+v"(l2));
         } else {
             q0 = sc.nodes[a + 0];
@@ -408,6 +410,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
                 const float4 q3 = sc.nodes[a + 3];
                 l2 = __float_as_int(q3.x);
                 l3 = __float_as_int(q3.y);
+                sc_y = q3.z; sc_z = q3.w;
                 qw = q3;
             }
             asm volatile("" : "+v"(l2), "+v"(l3));
@@ -423,12 +426,8 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
               for (int e = 0; e < 32; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(z));
               asm volatile("" :: "v"(z)); }
 #endif
-            const uint32_t meta = __float_as_uint(q0.w);
-            const float sx = __uint_as_float((meta & 0xffu) << 23) * idx;
-            const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy;
-            const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+            const float sx = q0.w * idx, sy = sc_y * idy, sz = sc_z * idz;  // per-axis grid step / direction
             const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
-            const int nch = (int)(meta >> 24);
             // entry/exit planes per axis follow the sign of the ray direction, so pick the packed
             // byte quadruples ONCE per node (6 v_cndmask) instead of min/max per child (24):
             // identical values to min(lo,hi)/max(lo,hi) of the reference's slab test
@@ -448,7 +447,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
                 const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
                 const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
                 const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
-                const bool hit = (k < nch) && (tmin <= tmax);
+                const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
                 key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
             }
             // sorting network for 4 keys: (0,1)(2,3)(0,2)(1,3)(1,2)
@@ -553,14 +552,11 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
             const int a = cur;
             const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2], q3 = sc.nodes[a + 3];
             int l2 = __float_as_int(q3.x), l3 = __float_as_int(q3.y);
+            const float sc_y = q3.z, sc_z = q3.w;
             asm volatile("" : "+v"(l2), "+v"(l3));
             if (COUNT) tc.inner++;
-            const uint32_t meta = __float_as_uint(q0.w);
-            const float sx = __uint_as_float((meta & 0xffu) << 23) * idx;
-            const float sy = __uint_as_float(((meta >> 8) & 0xffu) << 23) * idy;
-            const float sz = __uint_as_float(((meta >> 16) & 0xffu) << 23) * idz;
+            const float sx = q0.w * idx, sy = sc_y * idy, sz = sc_z * idz;  // per-axis grid step / direction
             const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
-            const int nch = (int)(meta >> 24);
             const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
             const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
             const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
@@ -576,7 +572,7 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
                 const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
                 const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
                 const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
-                const bool hit = (k < nch) && (tmin <= tmax);
+                const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
                 key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
             }
 #define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
