@@ -83,6 +83,12 @@ __device__ __forceinline__ v3 pt_hit_normal(const KScene& sc, const Hit& h) {
     return V3(q3.x, q3.y, q3.z);
 }
 
+// true in exactly one of the lanes that execute this call together
+__device__ __forceinline__ bool pt_first_active_lane() {
+    const unsigned long long m = __ballot(true);
+    return (__ffsll((long long)m) - 1) == (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+}
+
 struct TravCount {
     uint32_t inner, tris, leaves;
     // wave-level schedule statistics (instrumented launches of the wide walk only; identical in
@@ -381,7 +387,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         const int n_node = __popcll(__ballot(is_node));
         // a record step costs about half a node step: run whichever advances more lanes per instruction
         const bool node_phase = n_node >= 2 * (n_live - n_node);
-        if (COUNT) {
+        if (COUNT && pt_first_active_lane()) {  // one lane of those in the walk books the wave's iteration
             if (node_phase) { tc.it_node++; tc.act_node += n_node; }
             else { tc.it_rec++; tc.act_rec += n_live - n_node; }
         }
@@ -543,7 +549,7 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
         const int n_node = __popcll(__ballot(has_node));
         const int n_rec = __popcll(__ballot(has_rec));
         const bool node_phase = n_node * vote_node >= n_rec * vote_rec;
-        if (COUNT) {
+        if (COUNT && pt_first_active_lane()) {
             if (node_phase) { tc.it_node++; tc.act_node += n_node; }
             else { tc.it_rec++; tc.act_rec += n_rec; }
         }
@@ -1179,6 +1185,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
     if (COUNT) {
         const uint32_t a = wave_sum_u32(n_rays), b = wave_sum_u32(tc.inner), c = wave_sum_u32(tc.tris);
         const uint32_t dd = wave_sum_u32(tc.leaves), e = wave_sum_u32(n_hits), f = wave_sum_u32(n_paths);
+        // the walk books its iterations in whichever lane is first among those inside it: sum the lanes
+        const uint32_t w_it_node = wave_sum_u32(tc.it_node), w_act_node = wave_sum_u32(tc.act_node);
+        const uint32_t w_it_rec = wave_sum_u32(tc.it_rec), w_act_rec = wave_sum_u32(tc.act_rec);
         if (lane == 0) {
             atomicAdd(&P.counters[0], (unsigned long long)a);
             atomicAdd(&P.counters[1], (unsigned long long)b);
@@ -1187,10 +1196,10 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             atomicAdd(&P.counters[4], (unsigned long long)e);
             atomicAdd(&P.counters[5], (unsigned long long)f);
             // schedule statistics, one contribution per wave (pt_get_wave_stats)
-            atomicAdd(&P.counters[6], (unsigned long long)tc.it_node);
-            atomicAdd(&P.counters[7], (unsigned long long)tc.act_node);
-            atomicAdd(&P.counters[8], (unsigned long long)tc.it_rec);
-            atomicAdd(&P.counters[9], (unsigned long long)tc.act_rec);
+            atomicAdd(&P.counters[6], (unsigned long long)w_it_node);
+            atomicAdd(&P.counters[7], (unsigned long long)w_act_node);
+            atomicAdd(&P.counters[8], (unsigned long long)w_it_rec);
+            atomicAdd(&P.counters[9], (unsigned long long)w_act_rec);
             atomicAdd(&P.counters[10], (unsigned long long)it_shade);
             atomicAdd(&P.counters[11], (unsigned long long)act_shade);
             atomicAdd(&P.counters[12], (unsigned long long)it_begin);

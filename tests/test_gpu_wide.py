@@ -172,3 +172,31 @@ def test_woop_ray_batch_is_refused(ptwoop):
         ptwoop.trace_rays(buf.ptr, 4, True, buf.ptr, buf.ptr, None)
     assert e.value.code == -5
     buf.free()
+
+
+def test_wave_statistics_are_consistent():
+    """pt_get_wave_stats (instrumented persistent wide walks): the schedule counters add up."""
+    _, bvh = bvh_of("cornell_dragon")
+    W, H = 640, 360
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    sph = g.reference_spheres()
+    for walk in (2, 4):
+        t = g.PathTracer(0)
+        try:
+            t.set_option(g.OPT_WALK, walk)
+            t.set_option(g.OPT_COUNTERS, 1)
+            acc, _ = gpu_render(t, bvh, sph, cam, p, 2)
+            c, w = t.counters(), t.wave_stats()
+            print(f"walk {walk}: {c} {w}")
+            assert c["paths"] == 2 * W * H and c["rays"] == 4 * c["paths"]       # closed room, depth 4
+            assert w["act_node"] == c["inner"]                                    # one active lane per node visit
+            assert w["act_shade"] == c["rays"] and w["act_begin"] == c["paths"]
+            for ph in ("node", "rec", "shade", "begin"):
+                assert 0 < w["act_" + ph] <= 64 * w["it_" + ph]
+            assert w["it_loop"] >= w["it_shade"]
+            if walk == 2:
+                assert w["act_rec"] <= c["tris"]      # the leaf loop tests further records inside one record step
+            else:
+                assert w["act_rec"] == c["tris"]
+        finally:
+            t.close()
