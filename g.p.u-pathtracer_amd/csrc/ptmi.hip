@@ -74,6 +74,10 @@ struct pt_ctx {
     size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 36;
+    int opt_roles_batch = 16;    // role-split kernel: finished lanes that make a tracer wave leave the walk
+    float4* d_roles_state = nullptr;   // role-split kernel: cold path state of every block's slots
+    size_t roles_state_bytes = 0;
+    bool roles_launched = false; // a role-split launch is in flight: pt_sync checks its error word
     int opt_vote_node = 1, opt_vote_rec = 1;
     int opt_refill = 8;          // idle lanes that trigger a refill (PT_OPT_REFILL)
     int opt_top = 64;            // nodes mirrored in LDS (PT_OPT_TOP_NODES)
@@ -148,6 +152,7 @@ int pt_create(int device, pt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;
     if ((e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
+    if ((e = hipMemset(c->d_counters, 0, 16 * sizeof(unsigned long long))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMemset"); }
     if ((e = hipMalloc(&c->d_queue, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int))) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipMalloc"); }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { pt_destroy(c); return hip_fail(nullptr, e, "hipGetDeviceProperties"); }
@@ -169,6 +174,7 @@ int pt_destroy(pt_ctx* c) {
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_samples);
+    (void)hipFree(c->d_roles_state);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -186,7 +192,7 @@ int pt_set_option(pt_ctx* c, int option, int value) {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
     switch (option) {
         case PT_OPT_KERNEL:
-            if (value != PT_KERNEL_AUTO && value != PT_KERNEL_MEGA_BVH2 && value != PT_KERNEL_PERSISTENT)
+            if (value != PT_KERNEL_AUTO && value != PT_KERNEL_MEGA_BVH2 && value != PT_KERNEL_PERSISTENT && value != PT_KERNEL_WAVEFRONT)
                 return fail(c, PT_ERR_UNSUPPORTED, "pt_set_option: kernel variant not available in this build");
             c->opt_kernel = value;
             return PT_OK;
@@ -211,6 +217,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
         case PT_OPT_WALK:
             if (value < 0 || value > 4 || value == 3) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while), 1 (unified-step), 2 (wide) or 4 (wide, postponed leaf)");
             c->opt_walk = value;
+            return PT_OK;
+        case PT_OPT_ROLES_BATCH:
+            if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: roles batch must be 1..64");
+            c->opt_roles_batch = value;
             return PT_OK;
         case PT_OPT_VOTE_NODE:
         case PT_OPT_VOTE_REC:
@@ -237,6 +247,15 @@ int pt_sync(pt_ctx* c) {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->roles_launched) {  // role-split kernel: did any wave run into its spin bound?
+        c->roles_launched = false;
+        unsigned long long e = 0;
+        HIP_TRY(c, hipMemcpy(&e, c->d_counters + 15, sizeof e, hipMemcpyDeviceToHost));
+        if (e) {
+            (void)hipMemset(c->d_counters + 15, 0, sizeof e);
+            return fail(c, PT_ERR_DEVICE, "role-split kernel: a wave gave up waiting on a block queue (code " + std::to_string(e) + "); the frame is incomplete");
+        }
+    }
     return PT_OK;
 }
 
@@ -603,7 +622,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     if (c->opt_timing) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    const bool persistent = c->opt_kernel == PT_KERNEL_PERSISTENT || c->opt_kernel == PT_KERNEL_AUTO;
+    const bool persistent = c->opt_kernel == PT_KERNEL_PERSISTENT || c->opt_kernel == PT_KERNEL_AUTO || c->opt_kernel == PT_KERNEL_WAVEFRONT;
     const int need = stack_for_depth(c->has_bvh ? c->max_depth : 0);
     (void)need;  // any depth <= 64 works with every LDS window: deeper entries overflow
     int lstk = c->opt_lstk ? c->opt_lstk : PT_STACK_CAP;
@@ -677,7 +696,40 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         else if (c->opt_occ == 5) PT_LAUNCH_ALG(COUNT, 5, LSTK); \
         else PT_LAUNCH_ALG(COUNT, 4, LSTK);                   \
     } while (0)
-    if (c->opt_counters) {
+    // role-split kernel (PT_KERNEL_WAVEFRONT): wide walk, exact records, a BVH and at least one bounce;
+    // anything else runs the persistent kernel
+    const bool roles = c->opt_kernel == PT_KERNEL_WAVEFRONT && walk == 2 && c->has_bvh && P.depth > 0 && !c->opt_counters && lstk == 16;
+    if (roles) {
+        P.batch = c->opt_roles_batch;
+        P.sc.n_top = 0;
+        const size_t rl = ((size_t)PT_ROLE_TRACERS * 64 * 16 + (size_t)PT_ROLE_SLOTS * (PT_SLOT_DW + 3) + RC_WORDS + 15 * PT_KSPHERES) * 4;
+        const size_t max_blocks = (size_t)c->n_cu * 8;
+        const size_t rs_need = max_blocks * PT_ROLE_SLOTS * PT_COLD_DW * sizeof(float);
+        if (rs_need > c->roles_state_bytes) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_roles_state);
+            c->d_roles_state = nullptr;
+            c->roles_state_bytes = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->d_roles_state, rs_need));
+            c->roles_state_bytes = rs_need;
+        }
+        P.roles_state = c->d_roles_state;
+        c->roles_launched = true;   // the kernel ORs into counters[15] if a wave gave up waiting (sticky until pt_sync)
+#define PT_LAUNCH_ROLES(OCC)                                                                                       \
+        do {                                                                                                       \
+            int per_cu = 0;                                                                                        \
+            HIP_TRY(c, allow_lds(k_trace_roles<OCC, 16>, rl));                                                     \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_roles<OCC, 16>, PT_BLOCK, rl) != hipSuccess || per_cu < 1) \
+                per_cu = 1;                                                                                        \
+            const int rblocks = (int)(((long)work_tiles * 64 + PT_ROLE_SLOTS - 1) / PT_ROLE_SLOTS);                \
+            hipLaunchKernelGGL((k_trace_roles<OCC, 16>), dim3(std::min(std::min(per_cu, 8) * c->n_cu, std::max(1, rblocks))), dim3(PT_BLOCK), rl, c->stream, P); \
+        } while (0)
+        if (c->opt_occ == 8) PT_LAUNCH_ROLES(8);
+        else if (c->opt_occ == 6) PT_LAUNCH_ROLES(6);
+        else if (c->opt_occ == 5) PT_LAUNCH_ROLES(5);
+        else PT_LAUNCH_ROLES(4);
+#undef PT_LAUNCH_ROLES
+    } else if (c->opt_counters) {
         if (lstk == 16) PT_LAUNCH_OCC(true, 16);
         else PT_LAUNCH_OCC(true, PT_STACK_CAP);
     } else {

@@ -82,7 +82,9 @@ enum {
     PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, one wave per 8x8 tile, bounce by bounce      */
     PT_KERNEL_MEGA_WIDE = 2, /* reserved: wide compressed nodes (not in this build)              */
     PT_KERNEL_PERSISTENT = 3,/* persistent waves: work queue, ballot/prefix-count lane refill    */
-    PT_KERNEL_WAVEFRONT = 4  /* reserved: stage-split generate / extend / shade (not in build)   */
+    PT_KERNEL_WAVEFRONT = 4  /* stage split inside a block: tracer waves and shader waves exchange
+                                rays through LDS queues between segments (wide walk only; other
+                                settings fall back to PT_KERNEL_PERSISTENT)                      */
 };
 
 enum {
@@ -107,6 +109,8 @@ enum {
                                  clamped to it (a wave must always have work to go to)          */
     PT_OPT_VOTE_NODE = 12,    /* walk 4: a wave runs a node step when                              */
     PT_OPT_VOTE_REC = 13,     /*   lanes_with_node * VOTE_NODE >= lanes_with_record * VOTE_REC (1, 1) */
+    PT_OPT_ROLES_BATCH = 14,  /* PT_KERNEL_WAVEFRONT: finished lanes (1..64) that make a tracer wave leave the
+                                 walk to hand its segments over and refill; default 16            */
     PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
                                  for Moller-Trumbore, what the reference kernel runs
                                  (cudaUtils.h:135-172; default, bit-exact vs the oracle);
