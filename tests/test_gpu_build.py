@@ -15,7 +15,7 @@ from test_gpu_parity import gpu_trace, golden_camera
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "mega-wide": (g.KERNEL_MEGA_BVH2, 2),
+VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "mega-wide": (g.KERNEL_MEGA_BVH2, 2), "role-split": (g.KERNEL_WAVEFRONT, 2),
             "persistent-unified": (g.KERNEL_PERSISTENT, 1), "mega-whilewhile": (g.KERNEL_MEGA_BVH2, 0)}
 
 
