@@ -1273,6 +1273,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
 #define PT_ROLE_T_LOW 16             // ready segments below which the shaders stop waiting for full passes
 #define PT_ROLE_HELP_MIN 8           // finished segments that make an idle TRACER wave take a shading pass
 #endif
+#ifndef PT_ROLE_BLOCK
+#define PT_ROLE_BLOCK 256            // threads per block: PT_ROLE_TRACERS tracer waves, the rest shade
+#endif
 #ifndef PT_ROLE_MIX
 #define PT_ROLE_MIX 0
 #endif
@@ -1379,13 +1382,13 @@ __device__ __forceinline__ void role_shade_pass(const KParams& P, int lane, int 
 }
 
 template <int OCC, int LSTK>
-__global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_roles(const KParams P) {
+__global__ void __launch_bounds__(PT_ROLE_BLOCK, OCC) k_trace_roles(const KParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NT = PT_ROLE_TRACERS, F = PT_ROLE_SLOTS;
     // blocks alternate between NT tracers and NT-1 (PT_ROLE_MIX): the shading share of the work sits
     // between one and two waves of four
     const int nt = NT - ((PT_ROLE_MIX && (blockIdx.x & 1)) ? 1 : 0);
-    const int NS = PT_BLOCK / 64 - nt;
+    const int NS = PT_ROLE_BLOCK / 64 - nt;
     constexpr int STK_OFF = 0, SLOT_OFF = NT * 64 * LSTK, SQ_OFF = SLOT_OFF + F * PT_SLOT_DW, TQ_OFF = SQ_OFF + F, FQ_OFF = TQ_OFF + F,
                   CTL = FQ_OFF + F;
     if (tid < 11 * PT_KSPHERES) {  // the spheres' attributes (11 floats each), then centre+radius as float4s
@@ -1394,7 +1397,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_roles(const KParams P) 
         LDSF(CTL + RC_WORDS + tid) = v;
         if (tid % 11 < 4) LDSF(CTL + RC_WORDS + 88 + 4 * (tid / 11) + tid % 11) = v;
     }
-    for (int i = tid; i < F; i += PT_BLOCK) { LDSI(SQ_OFF + i) = 0; LDSI(TQ_OFF + i) = 0; LDSI(FQ_OFF + i) = i + 1; }
+    for (int i = tid; i < F; i += PT_ROLE_BLOCK) { LDSI(SQ_OFF + i) = 0; LDSI(TQ_OFF + i) = 0; LDSI(FQ_OFF + i) = i + 1; }
     if (tid < RC_WORDS) LDSI(CTL + tid) = tid == RC_FQ_TAIL ? F : 0;
     __syncthreads();
     const bool cull = P.cull != 0;
@@ -1494,6 +1497,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_roles(const KParams P) 
 #endif
     } else {
         // ------------------------------------------------------------------ shader wave
+#ifdef PT_ROLE_SHADER_PRIO
+        __builtin_amdgcn_s_setprio(PT_ROLE_SHADER_PRIO);   // the block's one shader wave is what the tracers wait for
+#endif
         const uint32_t slots_per_sample = (uint32_t)P.n_tiles * 64u;
         const uint32_t total = slots_per_sample * (P.samples ? P.spp : 1u);
         const uint32_t chunk = (uint32_t)P.chunk;

@@ -719,10 +719,10 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         do {                                                                                                       \
             int per_cu = 0;                                                                                        \
             HIP_TRY(c, allow_lds(k_trace_roles<OCC, 16>, rl));                                                     \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_roles<OCC, 16>, PT_BLOCK, rl) != hipSuccess || per_cu < 1) \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_roles<OCC, 16>, PT_ROLE_BLOCK, rl) != hipSuccess || per_cu < 1) \
                 per_cu = 1;                                                                                        \
             const int rblocks = (int)(((long)work_tiles * 64 + PT_ROLE_SLOTS - 1) / PT_ROLE_SLOTS);                \
-            hipLaunchKernelGGL((k_trace_roles<OCC, 16>), dim3(std::min(std::min(per_cu, 8) * c->n_cu, std::max(1, rblocks))), dim3(PT_BLOCK), rl, c->stream, P); \
+            hipLaunchKernelGGL((k_trace_roles<OCC, 16>), dim3(std::min(std::min(per_cu, 8) * c->n_cu, std::max(1, rblocks))), dim3(PT_ROLE_BLOCK), rl, c->stream, P); \
         } while (0)
         if (c->opt_occ == 8) PT_LAUNCH_ROLES(8);
         else if (c->opt_occ == 6) PT_LAUNCH_ROLES(6);
