@@ -690,19 +690,18 @@ __device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uin
     ps.depth = 0;
 }
 
-// One bounce after the closest triangle hit `h` is known (tracer.cu:98-296).  Returns true
-// when the sample is complete (col_out valid), false when ps holds the next ray segment.
+// What a segment ended on once the spheres have been tested too (intersectAllSpeheres,
+// cudaUtils.h:221-236, after the triangle hit of the walk): the distance, GeoType and sphere number.
+struct SceneHit {
+    float t;
+    int geom;     // 0 triangle, 1 sphere, 3 nothing (GeoType, CommomStructs.hpp)
+    int sph_id;
+};
+
 // sph_tab: float index into the dynamic LDS of a copy of the first PT_KSPHERES spheres (11 floats
-// each), or -1: the winner's attributes are then one short LDS gather instead of a global one.
-__device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out, int sph_tab = -1) {
-    PT_KARGS(K);   // shading scalars: read where they are used (see the sphere loop)
-    const v3 o = ps.o, d = ps.d;
-    // the triangle's normal is asked for NOW: its latency hides behind the sphere tests
-    v3 tri_n = V3(0.f, 0.f, 0.f);
-    if (h.tri != -1) tri_n = pt_hit_normal(P.sc, h);
-    v3 mask = ps.mask, accu = ps.accu;
-    pt_rng rng = ps.rng;
-    {
+// each, then centre+radius as float4s), or -1 = read the kernel arguments.
+__device__ __forceinline__ SceneHit pt_closest_sphere(const KParams& P, v3 o, v3 d, const Hit& h, int sph_tab = -1) {
+    PT_KARGS(K);
     int geom = 3;  // GeoType::NONE
     int sph_id = -1;
     float scene_t = h.t;
@@ -743,6 +742,25 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
             if (ts != 0.0f && ts < scene_t && ts > 0.01f) { scene_t = ts; sph_id = i; geom = 1; }
         }
     }
+    SceneHit sh;
+    sh.t = scene_t; sh.geom = geom; sh.sph_id = sph_id;
+    return sh;
+}
+
+// One bounce after the closest triangle hit `h` and the sphere tests `sh` are known
+// (tracer.cu:98-296).  Returns true when the sample is complete (col_out valid), false when ps
+// holds the next ray segment.  With sph_tab >= 0 the winner sphere's attributes are one short LDS
+// gather instead of a global one.
+// tri_n: pt_hit_normal of the walk's triangle hit (read only when the triangle is what was hit; the
+// caller fetches it early so that the latency hides behind other work).
+__device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, const Hit& h, const SceneHit& sh, v3 tri_n, v3& col_out, int sph_tab = -1) {
+    PT_KARGS(K);   // shading scalars: read where they are used (see the sphere loop)
+    const v3 o = ps.o, d = ps.d;
+    v3 mask = ps.mask, accu = ps.accu;
+    pt_rng rng = ps.rng;
+    {
+    const int geom = sh.geom, sph_id = sh.sph_id;
+    const float scene_t = sh.t;
     v3 hitpos = vmadd(d, scene_t, o);
     v3 n, nl, objcol, emit;
     int mat;
@@ -876,6 +894,15 @@ __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, cons
     ps.depth++;
     if (ps.depth >= P.depth) { col_out = accu; return true; }  // tracer.cu:305
     return false;
+}
+
+// spheres + shading in one go (the kernels that shade in the lane that walked)
+__device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out, int sph_tab = -1) {
+    // the triangle's normal is asked for NOW so that its latency hides behind the sphere tests
+    v3 tri_n = V3(0.f, 0.f, 0.f);
+    if (h.tri != -1) tri_n = pt_hit_normal(P.sc, h);
+    const SceneHit sh = pt_closest_sphere(P, ps.o, ps.d, h, sph_tab);
+    return path_shade_hit(P, ps, h, sh, tri_n, col_out, sph_tab);
 }
 
 // running mean with per-frame clamp, tracer.cu:386-391
@@ -1422,7 +1449,7 @@ __global__ void __launch_bounds__(PT_ROLE_BLOCK, OCC) k_trace_roles(const KParam
         for (;;) {
             // 1. finished segments -> shade queue
             const bool fin = slot >= 0 && !walking;
-            if (fin) {
+            if (fin) {   // (running the sphere tests here, on the lanes that just finished, costs +11 %: measured)
                 const int b = SLOT_OFF + slot * PT_SLOT_DW;
                 LDSF(b + 6) = ts.h.t; LDSI(b + 7) = ts.h.tri; LDSI(b + 8) = ts.h.rec;
             }
