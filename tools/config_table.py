@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE.json configuration on one GPU: exact segment counts
+(instrumented replay of the same frames) over the mean kernel time of the timed launches.
+Usage: python tools/config_table.py [--frames 10]"""
+import argparse, os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import gpu_pathtracer_amd as g
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=10)
+a = ap.parse_args()
+
+CONFIGS = [
+    # name, scene, W, H, spp per call, material, spheres
+    ("C2 cornell 1280x720, sphere room", "cornell", 1280, 720, 16, g.MAT_DIFF, True),
+    ("C2 cornell 1280x720, no spheres (open)", "cornell", 1280, 720, 16, g.MAT_DIFF, False),
+    ("C3 cornell_dragon 100k 1920x1080 diffuse", "cornell_dragon", 1920, 1080, 16, g.MAT_DIFF, True),
+    ("C3 cornell_dragon 800k 1920x1080 diffuse", "cornell_dragon_800k", 1920, 1080, 16, g.MAT_DIFF, True),
+    ("C3 cornell_dragon 800k 1920x1080 metal", "cornell_dragon_800k", 1920, 1080, 16, g.MAT_METAL, True),
+    ("C3 cornell_dragon 800k 1920x1080 specular", "cornell_dragon_800k", 1920, 1080, 16, g.MAT_SPEC, True),
+    ("C3 cornell_dragon 800k 1920x1080 diffuse, 1 spp per call", "cornell_dragon_800k", 1920, 1080, 1, g.MAT_DIFF, True),
+    ("C4 gto_sixteen 1920x1080", "gto_sixteen", 1920, 1080, 16, g.MAT_DIFF, True),
+    ("C5 dragon 4096x4096 8 spp (open)", "dragon", 4096, 4096, 8, g.MAT_DIFF, False),
+]
+print(f"{'configuration':62s} {'kernel':>10s} {'ms/call':>9s} {'Msegments':>10s} {'Mrays/s':>9s}")
+for name, scene, W, H, spp, mat, spheres in CONFIGS:
+    mesh = g.scene_mesh(scene)
+    bvh = g.Bvh(mesh)
+    for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("role-split", g.KERNEL_WAVEFRONT)):
+        pt = g.PathTracer(0)
+        pt.set_option(g.OPT_KERNEL, kern)
+        pt.upload_bvh(bvh)
+        pt.upload_spheres(g.reference_spheres() if spheres else None)
+        cam = g.default_camera(W, H)
+        acc, rgba = pt.alloc_frame(W, H)
+        def launch(f):
+            p = g.default_params(W, H, tri_mat=mat)
+            p.frame, p.sample_index, p.flags = f * spp, 1 + f * spp, g.FLAG_WRITE_RGBA
+            pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+        for f in range(2):
+            launch(f)
+        pt.sync()
+        t0 = time.perf_counter()
+        for f in range(a.frames):
+            launch(2 + f)
+        pt.sync()
+        ms = (time.perf_counter() - t0) / a.frames * 1e3
+        # exact segments of the same frames (instrumented persistent kernel: same paths, same counts)
+        pt.set_option(g.OPT_KERNEL, g.KERNEL_PERSISTENT)
+        pt.set_option(g.OPT_COUNTERS, 1)
+        seg = 0
+        n_c = min(a.frames, 2)
+        for f in range(n_c):
+            launch(2 + f)
+            pt.sync()
+            seg += pt.counters()["rays"]
+        seg /= n_c
+        print(f"{name:62s} {kname:>10s} {ms:9.3f} {seg / 1e6:10.2f} {seg / ms / 1e3:9.1f}", flush=True)
+        acc.free(); rgba.free(); pt.close()
