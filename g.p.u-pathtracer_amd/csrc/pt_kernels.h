@@ -61,6 +61,7 @@ struct KParams {
     unsigned int* queue;
     int batch;
     int refill;   // idle lanes that trigger a refill from the queue
+    int sph_tab;              // float index into the dynamic LDS of the sphere table (persistent kernel), -1 = none
     float4* roles_state;      // role-split kernel: cold path state, [block][slot][PT_COLD_DW] floats
     int vote_node, vote_rec;  // postponed-leaf walk: node step when n_node*vote_node >= n_rec*vote_rec
     int chunk;    // tile-ordered pixel slots per queue fetch (<= PT_CHUNK)
@@ -1079,6 +1080,12 @@ enum { PH_IDLE = 0, PH_TRAV = 1, PH_SHADE = 2 };
 template <bool COUNT, int OCC, int LSTK, int ALG>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KParams P) {
     float4* s_top = s_dyn;
+    if (P.sph_tab >= 0 && threadIdx.x < 11 * PT_KSPHERES) {  // sphere attributes + centres for the shading code (see path_shade)
+        PT_KARGS(K);
+        const float v = ((const __attribute__((address_space(4))) float*)&K.ksph[0])[threadIdx.x];
+        ((float*)s_dyn)[P.sph_tab + threadIdx.x] = v;
+        if (threadIdx.x % 11 < 4) ((float*)s_dyn)[P.sph_tab + 88 + 4 * (threadIdx.x / 11) + threadIdx.x % 11] = v;
+    }
     lds_load_top<PT_BLOCK>(P.sc, s_top);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1207,7 +1214,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                 done = true;
             } else {
                 if (COUNT) { n_rays++; n_hits += (ts.h.tri != -1); }
-                done = path_shade(P, ps, ts.h, col);
+                done = path_shade(P, ps, ts.h, col, P.sph_tab);
             }
             if (!done) {
                 if (P.sc.has_bvh) {

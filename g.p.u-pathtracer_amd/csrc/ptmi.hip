@@ -74,6 +74,7 @@ struct pt_ctx {
     size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 36;
+    int opt_sph_lds = 1;         // persistent kernel: sphere attributes from an LDS copy (PT_OPT_SPHERE_LDS)
     int opt_roles_batch = 16;    // role-split kernel: finished lanes that make a tracer wave leave the walk
     float4* d_roles_state = nullptr;   // role-split kernel: cold path state of every block's slots
     size_t roles_state_bytes = 0;
@@ -218,6 +219,7 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value < 0 || value > 4 || value == 3) return fail(c, PT_ERR_INVALID, "pt_set_option: walk must be 0 (while-while), 1 (unified-step), 2 (wide) or 4 (wide, postponed leaf)");
             c->opt_walk = value;
             return PT_OK;
+        case PT_OPT_SPHERE_LDS: c->opt_sph_lds = value != 0; return PT_OK;
         case PT_OPT_ROLES_BATCH:
             if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: roles batch must be 1..64");
             c->opt_roles_batch = value;
@@ -644,6 +646,11 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     while (lds > 160 * 1024 && P.sc.n_top > 0) {  // deep tree: give the LDS to the stack first
         P.sc.n_top /= 2;
         lds = lds_bytes(P.sc.n_top, lstk, PT_BLOCK);
+    }
+    P.sph_tab = -1;
+    if (persistent && c->opt_sph_lds) {   // sphere table behind the stacks (and the LDS mirror)
+        P.sph_tab = (int)(lds / 4);
+        lds += 15 * PT_KSPHERES * 4;
     }
     if (persistent) {
         P.queue = c->d_queue;

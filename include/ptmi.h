@@ -111,6 +111,8 @@ enum {
     PT_OPT_VOTE_REC = 13,     /*   lanes_with_node * VOTE_NODE >= lanes_with_record * VOTE_REC (1, 1) */
     PT_OPT_ROLES_BATCH = 14,  /* PT_KERNEL_WAVEFRONT: finished lanes (1..64) that make a tracer wave leave the
                                  walk to hand its segments over and refill; default 16            */
+    PT_OPT_SPHERE_LDS = 15,   /* persistent kernel: 1 (default) = the shading code reads the spheres from an LDS
+                                 copy instead of scalar / global loads                            */
     PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
                                  for Moller-Trumbore, what the reference kernel runs
                                  (cudaUtils.h:135-172; default, bit-exact vs the oracle);

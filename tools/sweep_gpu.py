@@ -30,6 +30,8 @@ for item in filter(None, a.bvh.split(",")):
     kw[k] = float(v) if k in ("split_alpha", "sah_tri_cost", "sah_node_cost") else int(v)
 pt = g.PathTracer(0)
 pt.set_option(g.OPT_LEAF_MAX, a.leaf_max)
+if "PT_SPH_LDS" in os.environ:
+    pt.set_option(g.OPT_SPHERE_LDS, int(os.environ["PT_SPH_LDS"]))
 if a.device_build:
     print("device build ms", pt.build_bvh(g.scene_mesh(a.scene)))
 else:
