@@ -7,7 +7,10 @@
 // Usage: pt_app --mesh assets/cornell.ptmesh [--width 1280 --height 720 --frames 16 --spp 1
 //               --depth 4 --mat 0..3 --no-spheres --no-materials --bk r g b --device 0
 //               --out image.ppm|.png|.pfm  --checkpoint state.ckpt [--checkpoint-every N]
-//               --resume state.ckpt]
+//               --resume state.ckpt --device-build --fix-estimators]
+// --device-build builds the BVH on the GPU (pt_build_bvh) instead of the host SAH/SBVH builder;
+// --fix-estimators sets the PT_FLAG_* corrected-estimator switches (face-forward, cosine DIFF,
+// glass fix, Russian roulette).
 // --frames counts samples per pixel in total; --spp of them are folded per pt_render call.
 // A mesh that carries materials (OBJ usemtl + .mtl, PTMESH2) is shaded with them
 // (pt_upload_tri_materials) unless --no-materials.  --resume continues a checkpointed
@@ -31,7 +34,7 @@ static int die(const char* what, const char* msg) {
 int main(int argc, char** argv) {
     std::string mesh_path, out_path, ckpt_path, resume_path;
     int W = 1280, H = 720, frames = 16, depth = 4, mat = PT_MAT_DIFF, device = 0, spp = 1, ckpt_every = 0;
-    bool spheres = true, use_materials = true;
+    bool spheres = true, use_materials = true, device_build = false, fix_estimators = false;
     float bk[3] = {1.f, 1.f, 1.f};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -49,6 +52,8 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--no-spheres") spheres = false;
         else if (a == "--no-materials") use_materials = false;
+        else if (a == "--device-build") device_build = true;
+        else if (a == "--fix-estimators") fix_estimators = true;
         else if (a == "--spp") spp = std::atoi(next("--spp"));
         else if (a == "--checkpoint") ckpt_path = next("--checkpoint");
         else if (a == "--checkpoint-every") ckpt_every = std::atoi(next("--checkpoint-every"));
@@ -62,18 +67,26 @@ int main(int argc, char** argv) {
     const bool is_ptmesh = mesh_path.size() > 7 && mesh_path.substr(mesh_path.size() - 7) == ".ptmesh";
     pth_mesh* mesh = is_ptmesh ? pth_mesh_load_ptmesh(mesh_path.c_str()) : pth_mesh_load_obj(mesh_path.c_str());
     if (!mesh) return die("mesh", pth_last_error());
-    pth_bvh* bvh = pth_bvh_build(mesh, nullptr);
-    if (!bvh) return die("bvh", pth_last_error());
-    pth_bvh_stats st;
-    pth_bvh_get_stats(bvh, &st);
-    std::printf("mesh %zu tris; bvh %llu inner, %llu leaves, depth %u, built in %.1f ms\n", pth_mesh_n_tris(mesh),
-                (unsigned long long)st.n_inner, (unsigned long long)st.n_leaves, st.max_depth, st.build_ms);
-
     pt_ctx* ctx = nullptr;
     if (pt_create(device, &ctx) != PT_OK) return die("pt_create", pt_last_error(nullptr));
-    if (pt_upload_bvh(ctx, pth_bvh_nodes(bvh), pth_bvh_n_node_vec4(bvh), pth_bvh_tris(bvh), pth_bvh_n_tri_vec4(bvh),
-                      pth_bvh_index(bvh), pth_bvh_n_index(bvh)) != PT_OK)
-        return die("pt_upload_bvh", pt_last_error(ctx));
+    pth_bvh* bvh = nullptr;
+    if (device_build) {
+        if (pt_build_bvh(ctx, pth_mesh_verts(mesh), pth_mesh_n_verts(mesh), pth_mesh_tris(mesh), pth_mesh_n_tris(mesh)) != PT_OK)
+            return die("pt_build_bvh", pt_last_error(ctx));
+        float bms = 0.f;
+        pt_last_build_ms(ctx, &bms);
+        std::printf("mesh %zu tris; bvh built on the device in %.2f ms\n", pth_mesh_n_tris(mesh), bms);
+    } else {
+        bvh = pth_bvh_build(mesh, nullptr);
+        if (!bvh) return die("bvh", pth_last_error());
+        pth_bvh_stats st;
+        pth_bvh_get_stats(bvh, &st);
+        std::printf("mesh %zu tris; bvh %llu inner, %llu leaves, depth %u, built in %.1f ms\n", pth_mesh_n_tris(mesh),
+                    (unsigned long long)st.n_inner, (unsigned long long)st.n_leaves, st.max_depth, st.build_ms);
+        if (pt_upload_bvh(ctx, pth_bvh_nodes(bvh), pth_bvh_n_node_vec4(bvh), pth_bvh_tris(bvh), pth_bvh_n_tri_vec4(bvh),
+                          pth_bvh_index(bvh), pth_bvh_n_index(bvh)) != PT_OK)
+            return die("pt_upload_bvh", pt_last_error(ctx));
+    }
     const bool has_materials = use_materials && pth_mesh_n_materials(mesh) > 0;
     if (has_materials) {
         static_assert(sizeof(pth_material) == sizeof(pt_material), "one layout");
@@ -118,6 +131,7 @@ int main(int argc, char** argv) {
     p.bk_color[0] = bk[0]; p.bk_color[1] = bk[1]; p.bk_color[2] = bk[2];
     p.air_ior = 1.0f; p.glass_ior = 1.4f; p.phong_expo = 30.f;
     p.flags = PT_FLAG_WRITE_RGBA;
+    if (fix_estimators) p.flags |= PT_FLAG_FACE_FORWARD | PT_FLAG_COSINE_DIFF | PT_FLAG_GLASS_FIX | PT_FLAG_RUSSIAN_ROULETTE;
     p.part_count = 1; p.part_rows = 8;
 
     void *accum = nullptr, *rgba = nullptr;
@@ -127,7 +141,7 @@ int main(int argc, char** argv) {
 
     // what a checkpoint must agree on to be continued: geometry size, image size, the scalar parameters
     uint64_t tag = pth_frame_hash((uint64_t)pth_mesh_n_tris(mesh) * 1315423911ull + (uint64_t)W * 65537u + (uint64_t)H);
-    tag = pth_frame_hash(tag ^ ((uint64_t)depth << 32 | (uint64_t)mat << 8 | (spheres ? 2u : 0u) | (has_materials ? 1u : 0u)));
+    tag = pth_frame_hash(tag ^ ((uint64_t)depth << 32 | (uint64_t)mat << 8 | (fix_estimators ? 4u : 0u) | (spheres ? 2u : 0u) | (has_materials ? 1u : 0u)));
 
     uint64_t frameNumber = 0, constantPdf = 0;   // constantPdf = samples folded so far
     std::vector<float> host_acc;
@@ -200,7 +214,7 @@ int main(int argc, char** argv) {
     pt_free(ctx, accum);
     pt_free(ctx, rgba);
     pt_destroy(ctx);
-    pth_bvh_free(bvh);
+    if (bvh) pth_bvh_free(bvh);
     pth_mesh_free(mesh);
     return 0;
 }

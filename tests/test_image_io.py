@@ -106,3 +106,20 @@ def test_app_resume_equals_uninterrupted_run(tmp_path):
     r = subprocess.run(common[:5] + ["--width", "160", "--height", "120", "--frames", "1", "--resume", str(tmp_path / "s.ckpt")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "checkpoint belongs to another" in r.stderr
+
+
+@pytest.mark.gpu
+def test_app_device_build_gives_the_same_picture(tmp_path):
+    """pt_app --device-build (pt_build_bvh) == pt_app over the host SAH/SBVH tree, bit for bit (the
+    closest hit does not depend on the tree; postponed nothing, exact records); --fix-estimators runs."""
+    mesh = os.path.join(ROOT, "assets", "bunny_low.ptmesh")
+    common = [APP, "--mesh", mesh, "--width", "480", "--height", "270", "--frames", "6", "--spp", "3", "--mat", "1"]
+    run = lambda extra: subprocess.run(common + extra, check=True, capture_output=True, text=True, timeout=300).stdout
+    run(["--out", str(tmp_path / "host.pfm")])
+    out = run(["--device-build", "--out", str(tmp_path / "dev.pfm")])
+    assert "built on the device" in out
+    a, b = read_pfm(tmp_path / "host.pfm"), read_pfm(tmp_path / "dev.pfm")
+    assert int(np.any(a != b, axis=-1).sum()) <= 2          # wide walk: grazing candidates (test_gpu_wide.py)
+    run(["--device-build", "--fix-estimators", "--out", str(tmp_path / "fix.pfm")])
+    c = read_pfm(tmp_path / "fix.pfm")
+    assert np.isfinite(c).all() and np.any(c != b)
