@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Soak test: many launches of every frame kernel at assorted sizes / spp / partitions; the persistent,
+role-split and mega kernels must produce the same accumulator every time (and pt_sync must never
+report the role-split kernel's watchdog).  Usage: python tools/soak_kernels.py [--rounds 40]"""
+import argparse, os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import gpu_pathtracer_amd as g
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=40)
+a = ap.parse_args()
+rng = np.random.default_rng(1)
+scenes = {n: g.Bvh(g.scene_mesh(n)) for n in ("cornell", "gto_sixteen", "cornell_dragon")}
+pts = {}
+for name, kern in (("persistent", g.KERNEL_PERSISTENT), ("role-split", g.KERNEL_WAVEFRONT), ("mega", g.KERNEL_MEGA_BVH2)):
+    pts[name] = g.PathTracer(0)
+    pts[name].set_option(g.OPT_KERNEL, kern)
+t0 = time.time()
+n_launch = 0
+for r in range(a.rounds):
+    scene = list(scenes)[r % len(scenes)]
+    W, H = int(rng.integers(2, 900)), int(rng.integers(2, 700))
+    spp = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    mat = int(rng.integers(0, 4))
+    spheres = bool(rng.integers(0, 4))
+    parts = int(rng.choice([1, 1, 2, 3]))
+    part = int(rng.integers(0, parts))
+    depth = int(rng.choice([1, 2, 4, 4, 7]))
+    cam = g.default_camera(max(W, 61), max(H, 61))
+    cam.aspect = W / H
+    res = {}
+    for name, pt in pts.items():
+        pt.upload_bvh(scenes[scene])
+        pt.upload_spheres(g.reference_spheres() if spheres else None)
+        acc, rgba = pt.alloc_frame(W, H + 64)
+        for f in range(3):
+            p = g.default_params(W, H, depth=depth, tri_mat=mat)
+            p.frame, p.sample_index, p.flags = f * spp, 1 + f * spp, g.FLAG_WRITE_RGBA
+            p.part_index, p.part_count, p.part_rows = part, parts, 8
+            pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+            n_launch += 1
+        pt.sync()
+        res[name] = acc.download(np.float32, (H, W, 3))
+        acc.free(); rgba.free()
+    ok = all(np.array_equal(res["persistent"], v, equal_nan=True) for v in res.values())
+    print(f"round {r}: {scene} {W}x{H} spp {spp} mat {mat} spheres {spheres} depth {depth} part {part}/{parts}: {'same' if ok else 'DIFFERENT'}", flush=True)
+    if not ok:
+        sys.exit(1)
+print(f"{n_launch} launches in {time.time() - t0:.1f} s: all kernels agree")
