@@ -1,0 +1,560 @@
+// pt_walks.h — the closest-hit walks over the item buffer (rows a5-a7 of SURVEY.md §8): stack, while-while,
+// unified-step, wide, wide with a postponed leaf.  Included by pt_kernels.h.
+#pragma once
+
+// ---------------------------------------------------------------------------------------
+// Binary-tree closest hit, same visiting order and arithmetic as cudaUtils.h:256-460 /
+// the CPU restatement, so results are bit-identical to it.
+//   - stack lives in LDS, laid out [entry][thread] → conflict-free for any mix of depths
+//   - slab tests: 12 v_fma + v_min3/v_max3 (the reference's PTX vmin/vmax trick is only
+//     valid for non-negative floats)
+//   - postponed-leaf exit on a 64-lane ballot (cudaUtils.h:383-394 is a 32-lane vote)
+// The walk is resumable: all of its state is in TravState, and run<DYN=true> returns early
+// when enough other lanes of the wave are waiting to be shaded / refilled (persistent
+// kernel); the per-ray sequence of tests is the same either way.
+//   - TOP: the first n_top nodes in breadth-first order (the levels every ray walks) are read
+//     from an LDS mirror laid out as four float4 planes.  rocprof showed the CU's vector
+//     memory pipe (TA/TD) ~90 % busy with 64-byte gathers and 70-80 % of node visits landing
+//     in the top few hundred nodes; ds_read_b128 runs on the LDS pipe instead.
+// Dynamic LDS of the kernels: [top-of-tree planes: 4 x n_top float4][stack: LSTK x BLOCK int].
+// One extern array so the carve base stays 16-byte aligned (cdna guide G17).
+extern __shared__ float4 s_dyn[];
+
+struct TravState {
+    float idx, idy, idz, oodx, oody, oodz;
+    int node, leaf, sp;
+    Hit h;
+};
+
+// Traversal stack: the first LSTK entries of every lane live in LDS ([entry][thread], so any
+// mix of depths is conflict-free); deeper entries — rare: the walk pushes one entry per level
+// that has both children hit — overflow into a private (scratch) array.  A small LSTK is what
+// lets 6-8 waves per SIMD fit in the CU's 160 KiB of LDS (64 B/lane at LSTK = 16).
+// lane id of the calling lane (v_mbcnt), opaque to the optimiser
+__device__ __forceinline__ int pt_lane_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <int LSTK>
+struct TravOverflow {
+    int e[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
+};
+
+template <int LSTK, int BLOCK>
+struct TravStack {
+    int base;  // WAVE-UNIFORM int index of lane 0's entry 0 inside s_dyn (the __shared__ symbol is
+               // named in the accessors so that the accesses stay ds_read/ds_write: a stored
+               // pointer makes hipcc merge the LDS and overflow paths into flat_load/flat_store)
+    // the overflow array is a SEPARATE private object: as a member it drags the whole struct,
+    // `base` included, into scratch memory (a scratch reload in front of every push)
+    int (&ovf)[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
+    int lane_base;  // base + lane id.  Re-deriving the lane id at every access (v_mbcnt x2 + add) was the
+                    // cheaper choice while ~120 SGPR spills ate the VGPR budget; with the kernel arguments
+                    // read at use, one VGPR here saves ~12 VALU per node step (-1.4 % / -3.3 % at 8 / 6 waves)
+    __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK>& o) : base(b), ovf(o.e), lane_base(b + pt_lane_fresh()) {}
+    __device__ __forceinline__ void put(int sp, int v) {
+        if (LSTK >= PT_STACK_CAP || sp < LSTK) {
+            ((int*)s_dyn)[lane_base + sp * BLOCK] = v;
+        } else {
+            asm volatile("" : "+v"(v));
+            ovf[sp - LSTK] = v;
+        }
+    }
+    __device__ __forceinline__ int get(int sp) const {
+        int v;
+        if (LSTK >= PT_STACK_CAP || sp < LSTK) {
+            v = ((const int*)s_dyn)[lane_base + sp * BLOCK];
+        } else {
+            v = ovf[sp - LSTK];
+            asm volatile("" : "+v"(v));
+        }
+        return v;
+    }
+};
+
+template <class STK>
+__device__ __forceinline__ void trav_begin(TravState& s, v3 o, v3 d, STK& stk, int root = 0) {
+    const float ooeps = 8.271806125530277e-25f;  // exp2f(-80), cudaUtils.h:283
+    s.idx = 1.0f / (fabsf(d.x) > ooeps ? d.x : copysignf(ooeps, d.x));
+    s.idy = 1.0f / (fabsf(d.y) > ooeps ? d.y : copysignf(ooeps, d.y));
+    s.idz = 1.0f / (fabsf(d.z) > ooeps ? d.z : copysignf(ooeps, d.z));
+    s.oodx = o.x * s.idx; s.oody = o.y * s.idy; s.oodz = o.z * s.idz;
+    s.sp = 0;
+    stk.put(0, PT_SENTINEL);
+    s.leaf = 0; s.node = root;
+    s.h.t = PT_F32_MAX; s.h.tri = -1; s.h.rec = 0;
+}
+
+// returns true when the walk is complete
+template <bool COUNT, bool DYN, bool TOP, class STK>
+__device__ __forceinline__ bool trav_run(TravState& s, const KScene& sc, v3 o, v3 d, bool cull,
+                                         STK& stk, TravCount& tc, int n_dead, int batch,
+                                         const float4* __restrict__ s_top) {
+    int node = s.node, leaf = s.leaf, sp = s.sp;
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    while (node != PT_SENTINEL) {
+        while ((unsigned)node < (unsigned)PT_SENTINEL) {  // node >= 0 && node != sentinel
+            float4 n0, n1, nz, nl;
+            if (TOP && node < sc.n_top * 4) {
+                // read through the __shared__ symbol itself and keep this a real branch: given
+                // a pointer parameter, hipcc if-converts the two paths into ONE generic-pointer
+                // select and emits eleven scalarised flat_load_dword per node
+                const int i = node >> 2;
+                n0 = s_dyn[i];
+                n1 = s_dyn[sc.n_top + i];
+                nz = s_dyn[2 * sc.n_top + i];
+                nl = s_dyn[3 * sc.n_top + i];
+                asm volatile("" : "+v"(n0.x), "+v"(nl.x));
+            } else {
+                n0 = sc.nodes[node + 0];
+                n1 = sc.nodes[node + 1];
+                nz = sc.nodes[node + 2];
+                nl = sc.nodes[node + 3];
+            }
+            int cx = __float_as_int(nl.x), cy = __float_as_int(nl.y);
+            // keep the link load with the three box loads: left alone, hipcc sinks it into the
+            // "hit" branch below, which makes every node visit two dependent round trips
+            asm volatile("" : "+v"(cx), "+v"(cy));
+            if (COUNT) tc.inner++;
+            const float c0lox = fmaf(n0.x, idx, -oodx), c0hix = fmaf(n0.y, idx, -oodx);
+            const float c0loy = fmaf(n0.z, idy, -oody), c0hiy = fmaf(n0.w, idy, -oody);
+            const float c1lox = fmaf(n1.x, idx, -oodx), c1hix = fmaf(n1.y, idx, -oodx);
+            const float c1loy = fmaf(n1.z, idy, -oody), c1hiy = fmaf(n1.w, idy, -oody);
+            const float c0loz = fmaf(nz.x, idz, -oodz), c0hiz = fmaf(nz.y, idz, -oodz);
+            const float c1loz = fmaf(nz.z, idz, -oodz), c1hiz = fmaf(nz.w, idz, -oodz);
+            const float c0min = fmaxf(fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fminf(c0loz, c0hiz)), 0.0f);
+            const float c0max = fminf(fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fmaxf(c0loz, c0hiz)), h.t);
+            const float c1min = fmaxf(fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fminf(c1loz, c1hiz)), 0.0f);
+            const float c1max = fminf(fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fmaxf(c1loz, c1hiz)), h.t);
+            const bool t0 = (c0min <= c0max) && (c0min >= 0.0f) && (c0min <= PT_F32_MAX);
+            const bool t1 = (c1min <= c1max) && (c1min >= 0.0f) && (c1min <= PT_F32_MAX);
+            if (!t0 && !t1) {
+                node = stk.get(sp);
+                sp--;
+            } else {
+                node = t0 ? cx : cy;
+                if (t0 && t1) {
+                    if (c1min < c0min) { int tmp = node; node = cy; cy = tmp; }
+                    sp++;
+                    stk.put(sp, cy);
+                }
+            }
+            if (node < 0 && leaf >= 0) {  // first leaf: postpone, keep descending
+                leaf = node;
+                node = stk.get(sp);
+                sp--;
+            }
+            if (!__ballot(leaf >= 0)) break;  // every active lane holds a leaf
+        }
+        while (leaf < 0) {
+            if (COUNT) tc.leaves++;
+            for (int a = ~leaf;; a += 4) {
+                const float4 r0 = sc.tris[a + 0];
+                const float4 r1 = sc.tris[a + 1];
+                const float4 r2 = sc.tris[a + 2];
+                if (COUNT) tc.tris++;
+                const v3 v0 = V3(r0.x, r0.y, r0.z), e1 = V3(r1.x, r1.y, r1.z), e2 = V3(r2.x, r2.y, r2.z);
+                const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+                const int id = __float_as_int(r0.w);
+                if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                    h.t = t;
+                    h.tri = id;
+                    h.rec = a;
+                }
+                if (__float_as_int(r1.w) != 0) break;  // last record of the leaf
+            }
+            leaf = node;
+            if (node < 0) {
+                node = stk.get(sp);
+                sp--;
+            }
+        }
+        if (DYN) {  // enough lanes are waiting for service: hand the wave back
+            const int active = __popcll(__ballot(1));
+            if (64 - active - n_dead >= batch) break;
+        }
+    }
+    s.node = node; s.leaf = leaf; s.sp = sp; s.h = h;
+    return node == PT_SENTINEL;
+}
+
+// ---------------------------------------------------------------------------------------
+// Unified-step walk: every iteration EVERY live lane advances by one 64-byte item — an inner
+// node (two slab tests) or one triangle record (Moller-Trumbore) — fetched by the same four
+// dwordx4 loads.  Why: rocprof shows the CU's vector-memory return path (TD) ~90 % busy at
+// ~16-20 cycles per dwordx4 WAVE instruction whatever the number of active lanes, and the
+// while-while walk above issues those instructions at ~26 % lane utilisation (lanes holding a
+// leaf idle through the node phase and vice versa).  Here one set of four loads serves all 64
+// lanes.  `cur` is the lane's item: >= 0 node, < 0 ~record, sentinel = done.  The set of
+// boxes/triangles a ray tests can differ slightly from the while-while order (a leaf is
+// tested as soon as it is popped, so later nodes see the shorter ray), the closest hit
+// (t, id, normal) cannot: ties go to the smaller id, so the result is order-independent.
+template <bool COUNT, bool DYN, class STK>
+__device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                                 TravCount& tc, int n_dead, int batch) {
+    int cur = s.node, sp = s.sp;
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    while (cur != PT_SENTINEL) {
+        const int a = cur >= 0 ? cur : ~cur;
+        const float4 q0 = sc.nodes[a + 0];
+        const float4 q1 = sc.nodes[a + 1];
+        const float4 q2 = sc.nodes[a + 2];
+        // 4th piece only for node lanes (links); a record's 4th piece (normal) is read on a hit.
+        // The CU's address/tag pipe costs ~1 cycle per LANE-level 16-byte load.
+        int cx = 0, cy = 0;
+        if (cur >= 0) {
+            const float4 q3 = sc.nodes[a + 3];
+            cx = __float_as_int(q3.x);
+            cy = __float_as_int(q3.y);
+        }
+        asm volatile("" : "+v"(cx), "+v"(cy));
+        if (cur >= 0) {
+            if (COUNT) tc.inner++;
+            const float c0lox = fmaf(q0.x, idx, -oodx), c0hix = fmaf(q0.y, idx, -oodx);
+            const float c0loy = fmaf(q0.z, idy, -oody), c0hiy = fmaf(q0.w, idy, -oody);
+            const float c1lox = fmaf(q1.x, idx, -oodx), c1hix = fmaf(q1.y, idx, -oodx);
+            const float c1loy = fmaf(q1.z, idy, -oody), c1hiy = fmaf(q1.w, idy, -oody);
+            const float c0loz = fmaf(q2.x, idz, -oodz), c0hiz = fmaf(q2.y, idz, -oodz);
+            const float c1loz = fmaf(q2.z, idz, -oodz), c1hiz = fmaf(q2.w, idz, -oodz);
+            const float c0min = fmaxf(fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fminf(c0loz, c0hiz)), 0.0f);
+            const float c0max = fminf(fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fmaxf(c0loz, c0hiz)), h.t);
+            const float c1min = fmaxf(fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fminf(c1loz, c1hiz)), 0.0f);
+            const float c1max = fminf(fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fmaxf(c1loz, c1hiz)), h.t);
+            const bool t0 = (c0min <= c0max) && (c0min >= 0.0f) && (c0min <= PT_F32_MAX);
+            const bool t1 = (c1min <= c1max) && (c1min >= 0.0f) && (c1min <= PT_F32_MAX);
+            if (!t0 && !t1) {
+                cur = stk.get(sp);
+                sp--;
+            } else {
+                cur = t0 ? cx : cy;
+                if (t0 && t1) {
+                    if (c1min < c0min) { int tmp = cur; cur = cy; cy = tmp; }
+                    sp++;
+                    stk.put(sp, cy);
+                }
+            }
+            if (COUNT && cur < 0) tc.leaves++;
+        } else {
+            if (COUNT) tc.tris++;
+            const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+            const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+            const int id = __float_as_int(q0.w);
+            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                h.t = t;
+                h.tri = id;
+                h.rec = a;
+            }
+            if (__float_as_int(q1.w) != 0) {  // last record of the leaf
+                cur = stk.get(sp);
+                sp--;
+                if (COUNT && cur < 0 && cur != PT_SENTINEL) tc.leaves++;
+            } else {
+                cur -= 4;  // ~(a + 4)
+            }
+        }
+        if (DYN) {  // enough lanes are waiting for service: hand the wave back
+            const int active = __popcll(__ballot(cur != PT_SENTINEL));
+            if (64 - active - n_dead >= batch) break;
+        }
+    }
+    s.node = cur; s.sp = sp; s.h = h;
+    return cur == PT_SENTINEL;
+}
+
+// ---------------------------------------------------------------------------------------
+// Wide walk: unified-step over the 4-wide quantised tree of pt_wide.h.  A node item tests four
+// child boxes (24 v_cvt_f32_ubyte + 24 v_fma + min/max), sorts the hit children by entry
+// distance with a 5-exchange network on (distance bits | child number) keys, continues with the
+// nearest and pushes the rest far-to-near.  Record items are the exact Moller-Trumbore test of
+// the other walks, so a reported hit is bit-identical to theirs; only the set of candidates the
+// (outward-rounded) boxes let through differs.  3 pieces for a record, 4 for a node.
+// WOOP: records hold Woop's affine rows (PT_OPT_TRI_TEST 1) instead of v0/e1/e2 — see
+// pt_woop_intersect in pt_math.h; tolerance-class parity (the triangle arithmetic differs).
+template <bool COUNT, bool DYN, bool TOP, bool WOOP, class STK>
+__device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                              TravCount& tc, int n_dead, int batch, int poll_index = -1, int poll_seen = 0) {
+    int cur = s.node, sp = s.sp;
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    int iter = 0;
+    for (;;) {
+        // role-split kernel: lanes that found the ready queue empty watch its tail (an LDS word) every
+        // 8th step, so that new segments are picked up while the other lanes are still walking
+        if (DYN && poll_index >= 0 && n_dead > 0 && (++iter & 7) == 0 &&
+            __atomic_load_n(&((int*)s_dyn)[poll_index], __ATOMIC_RELAXED) != poll_seen) break;
+        // phase vote: the wave runs ONE kind of step per iteration, the kind most live lanes are
+        // waiting for; the others sit this iteration out.  Node and record lanes no longer both
+        // pay for each other's code every iteration (the limiter is VALU issue).
+        // The loop is wave-uniform: every lane that entered stays until the common exit.
+        const bool live = cur != PT_SENTINEL;
+        const bool is_node = live && cur >= 0;
+        const int n_live = __popcll(__ballot(live));
+        if (n_live == 0) break;
+        if (DYN && 64 - n_live - n_dead >= batch) break;  // enough lanes wait for service
+        const int n_node = __popcll(__ballot(is_node));
+        // a record step costs about half a node step: run whichever advances more lanes per instruction
+        const bool node_phase = n_node >= 2 * (n_live - n_node);
+        if (COUNT && pt_first_active_lane()) {  // one lane of those in the walk books the wave's iteration
+            if (node_phase) { tc.it_node++; tc.act_node += n_node; }
+            else { tc.it_rec++; tc.act_rec += n_live - n_node; }
+        }
+        if (!live || is_node != node_phase) continue;
+        const int a = cur >= 0 ? cur : ~cur;
+        float4 q0, q1, q2;
+        float4 qw = make_float4(0.f, 0.f, 0.f, 0.f);  // WOOP: a record's 4th piece (normal | id<<1|last)
+        int l2 = 0, l3 = 0;
+        float sc_y = 0.f, sc_z = 0.f;
+        const int ti = a - sc.top_base;
+        if (TOP && cur >= 0 && (unsigned)ti < (unsigned)(sc.n_top * 4)) {
+            const int i = ti >> 2;
+            q0 = s_dyn[i];
+            q1 = s_dyn[sc.n_top + i];
+            q2 = s_dyn[2 * sc.n_top + i];
+            const float4 q3 = s_dyn[3 * sc.n_top + i];
+            l2 = __float_as_int(q3.x);
+            l3 = __float_as_int(q3.y);
+            sc_y = q3.z; sc_z = q3.w;
+            asm volatile("" : "+v"(q0.x), "+v"(l2));
+        } else {
+            q0 = sc.nodes[a + 0];
+            q1 = sc.nodes[a + 1];
+            q2 = sc.nodes[a + 2];
+            if (WOOP || cur >= 0) {
+                const float4 q3 = sc.nodes[a + 3];
+                l2 = __float_as_int(q3.x);
+                l3 = __float_as_int(q3.y);
+                sc_y = q3.z; sc_z = q3.w;
+                qw = q3;
+            }
+            asm volatile("" : "+v"(l2), "+v"(l3));
+        }
+        if (cur >= 0) {
+            if (COUNT) tc.inner++;
+#ifdef PT_EXP_LOAD   // sensitivity experiment: one more 16-byte access to the node's line per node step
+            { const float4 dummy = sc.nodes[a + 3]; asm volatile("" :: "v"(dummy.x), "v"(dummy.w)); }
+#endif
+#ifdef PT_EXP_VALU   // sensitivity experiment: 32 more dependent VALU instructions per node step
+            { float z = q0.x;
+#pragma unroll
+              for (int e = 0; e < 32; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(z));
+              asm volatile("" :: "v"(z)); }
+#endif
+            const float sx = q0.w * idx, sy = sc_y * idy, sz = sc_z * idz;  // per-axis grid step / direction
+            const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
+            // entry/exit planes per axis follow the sign of the ray direction, so pick the packed
+            // byte quadruples ONCE per node (6 v_cndmask) instead of min/max per child (24):
+            // identical values to min(lo,hi)/max(lo,hi) of the reference's slab test
+            const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
+            const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
+            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+            const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx;
+            const uint32_t ny = py ? qly : qhy, fy = py ? qhy : qly;
+            const uint32_t nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
+            const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
+            uint32_t key[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // (entry, exit) of one axis in one v_pk_fma_f32
+                const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
+                const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
+                const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
+                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
+                const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
+                key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
+            }
+            // sorting network for 4 keys: (0,1)(2,3)(0,2)(1,3)(1,2)
+#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+#define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
+            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
+            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
+            if (key[1] != 0xffffffffu) {
+                const int lk = PT_LINK(key[1]);
+                sp++;
+                stk.put(sp, lk);
+            }
+            if (key[0] != 0xffffffffu) {
+                cur = PT_LINK(key[0]);
+            } else {
+                cur = stk.get(sp);
+                sp--;
+            }
+#undef PT_LINK
+            if (COUNT && cur < 0) tc.leaves++;
+        } else {
+            if (COUNT) tc.tris++;
+            float t;
+            int id;
+            bool last;
+            if (WOOP) {
+                t = pt_woop_intersect(q0, q1, q2, V3(qw.x, qw.y, qw.z), o, d, cull);
+                id = __float_as_int(qw.w) >> 1;
+                last = (__float_as_int(qw.w) & 1) != 0;
+            } else {
+                const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+                t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+                id = __float_as_int(q0.w);
+                last = __float_as_int(q1.w) != 0;
+            }
+            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                h.t = t;
+                h.tri = id;
+                h.rec = a;
+            }
+            // finish the leaf inside THIS iteration: its next record sits in the same or the next cache
+            // line, so the extra fetch is short, and the wave saves a vote + a phase switch per record
+            // (-1.4 % at 8 waves/SIMD, -3 % at 5-6)
+            if (!WOOP) {
+                int aa = a;
+                while (!last) {
+                    aa += 4;
+                    const float4 r0 = sc.nodes[aa], r1 = sc.nodes[aa + 1], r2 = sc.nodes[aa + 2];
+                    if (COUNT) tc.tris++;
+                    const float t2 = pt_mt_intersect(V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), V3(r2.x, r2.y, r2.z), o, d, cull);
+                    const int id2 = __float_as_int(r0.w);
+                    last = __float_as_int(r1.w) != 0;
+                    if (t2 > 0.0f && (t2 < h.t || (t2 == h.t && h.tri != -1 && id2 < h.tri))) {
+                        h.t = t2;
+                        h.tri = id2;
+                        h.rec = aa;
+                    }
+                }
+            }
+            if (last) {  // last record of the leaf
+                cur = stk.get(sp);
+                sp--;
+                if (COUNT && cur < 0 && cur != PT_SENTINEL) tc.leaves++;
+            } else {
+                cur -= 4;  // ~(a + 4)
+            }
+        }
+    }
+    s.node = cur; s.sp = sp; s.h = h;
+    return cur == PT_SENTINEL;
+}
+
+// Wide walk with ONE postponed leaf per lane (Aila-Laine's trick, restated for the phase vote):
+// a lane that reaches a leaf parks it in `pend` and goes on with the next stack entry, so it can
+// take part in node steps AND in record steps; it only waits when it holds a parked leaf and
+// reaches a second one.  The closest hit is order independent (every pruning test uses a valid
+// upper bound h.t, equal-t ties go to the smaller id), so the result is bit-identical to the
+// other walks; parking a leaf only delays the tightening of h.t by a few node steps.
+template <bool COUNT, bool DYN, class STK>
+__device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                                   TravCount& tc, int n_dead, int batch, int vote_node, int vote_rec) {
+    int cur = s.node, sp = s.sp, pend = s.leaf;  // pend: ~address of the next record of the parked leaf, 0 = none
+    Hit h = s.h;
+    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    for (;;) {
+        const bool has_node = (unsigned)cur < (unsigned)PT_SENTINEL;
+        const bool has_rec = pend != 0;
+        const int n_live = __popcll(__ballot(has_node || has_rec));
+        if (n_live == 0) break;
+        if (DYN && 64 - n_live - n_dead >= batch) break;  // enough lanes wait for service
+        const int n_node = __popcll(__ballot(has_node));
+        const int n_rec = __popcll(__ballot(has_rec));
+        const bool node_phase = n_node * vote_node >= n_rec * vote_rec;
+        if (COUNT && pt_first_active_lane()) {
+            if (node_phase) { tc.it_node++; tc.act_node += n_node; }
+            else { tc.it_rec++; tc.act_rec += n_rec; }
+        }
+        if (node_phase) {
+            if (!has_node) continue;
+            const int a = cur;
+            const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2], q3 = sc.nodes[a + 3];
+            int l2 = __float_as_int(q3.x), l3 = __float_as_int(q3.y);
+            const float sc_y = q3.z, sc_z = q3.w;
+            asm volatile("" : "+v"(l2), "+v"(l3));
+            if (COUNT) tc.inner++;
+            const float sx = q0.w * idx, sy = sc_y * idy, sz = sc_z * idz;  // per-axis grid step / direction
+            const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
+            const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
+            const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
+            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+            const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx;
+            const uint32_t ny = py ? qly : qhy, fy = py ? qhy : qly;
+            const uint32_t nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
+            const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
+            uint32_t key[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
+                const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
+                const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
+                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
+                const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
+                key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
+            }
+#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+#define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
+            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
+            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
+            if (key[1] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[1])); }
+            if (key[0] != 0xffffffffu) {
+                cur = PT_LINK(key[0]);
+            } else {
+                cur = stk.get(sp);
+                sp--;
+            }
+#undef PT_LINK
+            if (COUNT && cur < 0) tc.leaves++;
+            if (cur < 0 && pend == 0) {  // park the leaf, go on with the next entry
+                pend = cur;
+                cur = stk.get(sp);
+                sp--;
+                if (COUNT && cur < 0) tc.leaves++;
+            }
+        } else {
+            if (!has_rec) continue;
+            const int a = ~pend;
+            const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2];
+            if (COUNT) tc.tris++;
+            const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
+            const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);
+            const int id = __float_as_int(q0.w);
+            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) {
+                h.t = t;
+                h.tri = id;
+                h.rec = a;
+            }
+            if (__float_as_int(q1.w) != 0) {  // last record of the leaf
+                pend = 0;
+                if (cur < 0) {  // a second leaf was waiting in cur
+                    pend = cur;
+                    cur = stk.get(sp);
+                    sp--;
+                }
+            } else {
+                pend -= 4;  // ~(a + 4)
+            }
+        }
+    }
+    s.node = cur; s.sp = sp; s.h = h; s.leaf = pend;
+    return cur == PT_SENTINEL && pend == 0;
+}
+
+template <bool COUNT, bool TOP, class STK>
+__device__ __forceinline__ Hit trav_bvh2(const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
+                                         TravCount& tc, const float4* __restrict__ s_top) {
+    TravState s;
+    trav_begin(s, o, d, stk);
+    trav_run<COUNT, false, TOP, STK>(s, sc, o, d, cull, stk, tc, 0, 0, s_top);
+    return s.h;
+}
+
+
+template <int BLOCK>
+__device__ __forceinline__ void lds_load_top(const KScene& sc, float4* __restrict__ s_top) {
+    for (int i = threadIdx.x; i < sc.n_top * 4; i += BLOCK) s_top[(i & 3) * sc.n_top + (i >> 2)] = sc.nodes[sc.top_base + i];
+    __syncthreads();
+}
+
