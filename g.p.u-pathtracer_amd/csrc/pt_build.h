@@ -99,19 +99,55 @@ __device__ __forceinline__ unsigned long long ptb_spread21(unsigned int v) {  //
     return x;
 }
 
+// Sort key.  Plain Morton order (PTB_SIZE_BITS 0): 21 bits per axis of the box centre.  Extended
+// Morton codes (Vinkler et al. 2017): every 7th bit is a bit of the box DIAGONAL, so that triangles
+// of very different size (32 wall triangles next to 800 000 dragon triangles) separate high in
+// the tree instead of dragging huge boxes down into fine clusters: 18 bits per axis + 9 size bits.
+#ifndef PTB_SIZE_BITS
+#define PTB_SIZE_BITS 9
+#endif
 __global__ void __launch_bounds__(PTB_BLOCK) k_morton(const BuildArrays B) {
     const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
     if (i >= B.n) return;
-    unsigned int q[3];
+    float u[3], diag2 = 0.f, sdiag2 = 0.f;
     for (int a = 0; a < 3; a++) {
         const float lo = ptb_unordered(B.cbounds[a]), hi = ptb_unordered(B.cbounds[3 + a]);
-        const float c = 0.5f * B.tbox[6 * (size_t)i + a] + 0.5f * B.tbox[6 * (size_t)i + 3 + a];
+        const float blo = B.tbox[6 * (size_t)i + a], bhi = B.tbox[6 * (size_t)i + 3 + a];
+        const float c = 0.5f * blo + 0.5f * bhi;
         const float ext = hi - lo;
-        float u = ext > 0.f ? (c - lo) / ext : 0.f;
-        u = fminf(fmaxf(u, 0.f), 1.f);
-        q[a] = min((unsigned int)(u * 2097152.0f), 2097151u);
+        u[a] = ext > 0.f ? fminf(fmaxf((c - lo) / ext, 0.f), 1.f) : 0.f;
+        diag2 += (bhi - blo) * (bhi - blo);
+        sdiag2 += ext * ext;
     }
-    B.key_in[i] = (ptb_spread21(q[0]) << 2) | (ptb_spread21(q[1]) << 1) | ptb_spread21(q[2]);
+    unsigned long long key;
+    if (PTB_SIZE_BITS == 0) {
+        unsigned int q[3];
+        for (int a = 0; a < 3; a++) q[a] = min((unsigned int)(u[a] * 2097152.0f), 2097151u);
+        key = (ptb_spread21(q[0]) << 2) | (ptb_spread21(q[1]) << 1) | ptb_spread21(q[2]);
+    } else {
+        const int AB = (63 - PTB_SIZE_BITS) / 3;                       // bits per axis
+        unsigned int q[3];
+        for (int a = 0; a < 3; a++) q[a] = min((unsigned int)(u[a] * (float)(1u << AB)), (1u << AB) - 1u);
+        const float rel = sdiag2 > 0.f ? sqrtf(diag2 / sdiag2) : 0.f;   // box diagonal / scene diagonal, 0..~1
+        const unsigned int qs = min((unsigned int)(fminf(rel, 1.f) * (float)(1u << PTB_SIZE_BITS)), (1u << PTB_SIZE_BITS) - 1u);
+        // most significant first: x y z x y z s, x y z x y z s, ...
+        key = 0;
+        int bx = AB - 1, bs = PTB_SIZE_BITS - 1, phase = 0;
+        int ax = 0;
+        for (int out = 0; out < 3 * AB + PTB_SIZE_BITS; out++) {
+            unsigned int bit;
+            if (phase == 6 && bs >= 0) { bit = (qs >> bs) & 1u; bs--; phase = 0; }
+            else {
+                bit = (q[ax] >> bx) & 1u;
+                ax++;
+                if (ax == 3) { ax = 0; bx--; }
+                phase++;
+                if (bx < 0) phase = 6;   // axes exhausted: the rest are size bits
+            }
+            key = (key << 1) | bit;
+        }
+    }
+    B.key_in[i] = key;
     B.val_in[i] = i;
 }
 
