@@ -1,13 +1,13 @@
 // pt_build.h — BVH construction ON the device (pt_build_bvh): the step in front
 // of the hot path.  The reference builds on the host (SplitBVHBuilder.cpp, 1.7 s per 100 k
-// triangles) and so does host/pthost.cpp (SAH/SBVH, ~1.4 s for 800 k); this is the fast
+// triangles) and so does host/pthost.cpp (SAH/SBVH, ~1.4 s for 800 k; here 2.4 ms); this is the fast
 // alternative for scenes that change: a linear BVH
 //   1. k_tri_bounds   triangle boxes + bounds of the box centres (ordered-int atomics)
 //   2. k_morton       63-bit Morton key of every centre (21 bits per axis)
 //   3. hipcub radix sort of (key, triangle)
 //   4. k_hierarchy    Karras 2012: every inner node finds its key range and split in parallel;
 //                     equal keys are told apart by their position, so the tree stays a tree
-//   5. k_fit          bottom-up boxes: the second thread to arrive at a node merges its children
+//   5. k_node_depth + k_fit_level   boxes bottom-up, one launch per tree level (no device fences)
 //   6. k_records      the 64-byte triangle records in sorted order; a subtree with <= leaf_max
 //                     triangles is ONE leaf (its records are contiguous), the last one flagged
 //   7. k_binary       the binary nodes in the Compact layout (walks 0/1, pt_trace_rays)
@@ -44,7 +44,7 @@ struct BuildArrays {
     int* parent_i;           // parent of inner node (root: -1)
     int* parent_l;           // parent of leaf position
     float* nbox;             // [n-1][6] box of the inner node
-    unsigned int* arrive;    // [n-1] fit counters
+    unsigned int* arrive;    // [n-1] depth of the inner node (level of the bottom-up fit)
     // outputs
     float4* items;           // [binary nodes n-1][records n][wide nodes <= n-1]
     unsigned int* stats;     // [0] wide nodes allocated [1] next-frontier size [2] leaves [3] max binary depth
@@ -75,17 +75,22 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_tri_bounds(const BuildArrays B) {
             B.tbox[6 * (size_t)i + 3 + a] = hi[a];
         }
     }
-    // wave reduction, then one atomic per wave and component
+    // wave reduction, block reduction through LDS, then ONE atomic per block and component (one per
+    // wave = 75 000 atomics on six addresses = 0.86 ms of serialised L2 atomics for 800 k triangles)
+    __shared__ unsigned int s_red[PTB_BLOCK / 64][6];
     for (int a = 0; a < 3; a++) {
         unsigned int mn = live ? ptb_ordered(c[a]) : 0xffffffffu, mx = live ? ptb_ordered(c[a]) : 0u;
         for (int off = 32; off > 0; off >>= 1) {
             mn = min(mn, (unsigned int)__shfl_xor((int)mn, off));
             mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&B.cbounds[a], mn);
-            atomicMax(&B.cbounds[3 + a], mx);
-        }
+        if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6][a] = mn; s_red[threadIdx.x >> 6][3 + a] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned int v = s_red[0][threadIdx.x];
+        for (int w = 1; w < PTB_BLOCK / 64; w++) v = threadIdx.x < 3 ? min(v, s_red[w][threadIdx.x]) : max(v, s_red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&B.cbounds[threadIdx.x], v); else atomicMax(&B.cbounds[threadIdx.x], v);
     }
 }
 
@@ -195,25 +200,33 @@ __device__ __forceinline__ void ptb_child_box(const BuildArrays& B, int c, float
     for (int a = 0; a < 6; a++) bx[a] = src[a];
 }
 
-// One thread per leaf walks towards the root; at every inner node the FIRST arrival stops and
-// the second — which therefore knows both children are finished — merges their boxes.
-__global__ void __launch_bounds__(PTB_BLOCK) k_fit(const BuildArrays B) {
-    const int j = blockIdx.x * PTB_BLOCK + threadIdx.x;
-    if (j >= B.n) return;
-    int cur = B.parent_l[j];
-    while (cur >= 0) {
-        __threadfence();                                   // my child's box is visible before I announce it
-        if (atomicAdd(&B.arrive[cur], 1u) == 0u) return;
-        __threadfence();                                   // the sibling's box is visible after its announcement
-        float a[6], b[6];
-        ptb_child_box(B, B.left[cur], a);
-        ptb_child_box(B, B.right[cur], b);
-        float* dst = B.nbox + 6 * (size_t)cur;
-        for (int k = 0; k < 3; k++) {
-            dst[k] = fminf(a[k], b[k]);
-            dst[3 + k] = fmaxf(a[k + 3], b[k + 3]);
-        }
-        cur = B.parent_i[cur];
+// Depth of every inner node (edges to the root) by walking the parent chain, and the deepest one.
+__global__ void __launch_bounds__(PTB_BLOCK) k_node_depth(const BuildArrays B) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    unsigned int depth = 0;
+    if (i < B.n - 1) {
+        for (int cur = B.parent_i[i]; cur >= 0; cur = B.parent_i[cur]) depth++;
+        B.arrive[i] = depth;
+    }
+    for (int off = 32; off > 0; off >>= 1) depth = max(depth, (unsigned int)__shfl_xor((int)depth, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&B.stats[3], depth);
+}
+
+// Boxes bottom-up, ONE LEVEL PER LAUNCH: the inner nodes of depth `level` merge their children,
+// which are leaves or nodes of depth level + 1 finished by the previous launch.  (The classic
+// single-launch version — second arrival at a node merges, a device-scope fence on either side of
+// the counter — spends 5.3 ms of an 8 ms build of 800 k triangles in those fences: on this part
+// they write back / invalidate an XCD's whole L2.  ~40 launches of a trivial kernel take 0.7 ms.)
+__global__ void __launch_bounds__(PTB_BLOCK) k_fit_level(const BuildArrays B, unsigned int level) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= B.n - 1 || B.arrive[i] != level) return;
+    float a[6], b[6];
+    ptb_child_box(B, B.left[i], a);
+    ptb_child_box(B, B.right[i], b);
+    float* dst = B.nbox + 6 * (size_t)i;
+    for (int k = 0; k < 3; k++) {
+        dst[k] = fminf(a[k], b[k]);
+        dst[3 + k] = fmaxf(a[k + 3], b[k + 3]);
     }
 }
 

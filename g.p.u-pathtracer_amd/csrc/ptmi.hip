@@ -422,7 +422,6 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     const unsigned int st0[4] = {1u, 0u, 0u, 0u};   // wide slot 0 is the root's
     HIP_TRY(c, hipMemcpyAsync(B.cbounds, cb0, sizeof cb0, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(B.stats, st0, sizeof st0, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync(B.arrive, 0, (size_t)n * sizeof(unsigned int), st));
     HIP_TRY(c, hipMemsetAsync(items, 0, n_items * 64, st));
     HIP_TRY(c, hipEventRecord(e0, st));
 
@@ -435,7 +434,15 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     HIP_TRY(c, tmp.get(&cub_tmp, cub_bytes));
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, B.key_in, B.key, B.val_in, B.val, n, 0, 63, st));
     hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, B);
-    hipLaunchKernelGGL(k_fit, grd, blk, 0, st, B);
+    hipLaunchKernelGGL(k_node_depth, grd, blk, 0, st, B);
+    HIP_TRY(c, hipGetLastError());
+    {   // bottom-up fit, one launch per level, deepest first
+        unsigned int deepest = 0;
+        HIP_TRY(c, hipMemcpyAsync(&deepest, B.stats + 3, sizeof deepest, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (deepest + 1 > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
+        for (unsigned int level = deepest + 1; level-- > 0;) hipLaunchKernelGGL(k_fit_level, grd, blk, 0, st, B, level);
+    }
     hipLaunchKernelGGL(k_depth, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_records, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_binary, grd, blk, 0, st, B);
