@@ -234,10 +234,7 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_fit_level(const BuildArrays B, un
 __global__ void __launch_bounds__(PTB_BLOCK) k_depth(const BuildArrays B) {
     const int j = blockIdx.x * PTB_BLOCK + threadIdx.x;
     unsigned int depth = 0;
-    if (j < B.n) {
-        int cur = B.parent_l[j];
-        while (cur >= 0) { depth++; cur = B.parent_i[cur]; }
-    }
+    if (j < B.n) depth = B.arrive[B.parent_l[j]] + 1u;   // the parent's depth is known (k_node_depth)
     for (int off = 32; off > 0; off >>= 1) depth = max(depth, (unsigned int)__shfl_xor((int)depth, off));
     if ((threadIdx.x & 63) == 0) atomicMax(&B.stats[3], depth);
 }
