@@ -1,6 +1,6 @@
 // pt_build.h — BVH construction ON the device (pt_build_bvh): the step in front
 // of the hot path.  The reference builds on the host (SplitBVHBuilder.cpp, 1.7 s per 100 k
-// triangles) and so does host/pthost.cpp (SAH/SBVH, ~1.4 s for 800 k; here 2.4 ms); this is the fast
+// triangles) and so does host/pthost.cpp (SAH/SBVH, ~1.4 s for 800 k; here 1.8 ms); this is the fast
 // alternative for scenes that change: a linear BVH
 //   1. k_tri_bounds   triangle boxes + bounds of the box centres (ordered-int atomics)
 //   2. k_morton       63-bit Morton key of every centre (21 bits per axis)
@@ -47,7 +47,8 @@ struct BuildArrays {
     unsigned int* arrive;    // [n-1] depth of the inner node (level of the bottom-up fit)
     // outputs
     float4* items;           // [binary nodes n-1][records n][wide nodes <= n-1]
-    unsigned int* stats;     // [0] wide nodes allocated [1] next-frontier size [2] leaves [3] max binary depth
+    unsigned int* stats;     // [0] wide nodes allocated [1] - [2] leaves [3] max binary depth
+    unsigned int* level_cnt; // [66] frontier size of every wide level (level 0 = 1: the root)
     int2* frontier_a; int2* frontier_b;   // (inner node, wide slot)
 };
 
@@ -303,9 +304,11 @@ __device__ __forceinline__ float ptb_area(const float* b) {
 // One level of the 4-wide tree: every frontier entry (inner node, wide slot) adopts up to four
 // descendants — the inner child with the largest box is opened first, as the host path does —
 // writes its node and queues its inner children for the next level.
-__global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, const int2* __restrict__ in, int n_in, int2* __restrict__ out) {
-    const int idx = blockIdx.x * PTB_BLOCK + threadIdx.x;
-    if (idx >= n_in) return;
+// The frontier sizes live on the device (level_cnt[level]), so the host queues every level without
+// reading anything back: a level whose frontier is empty costs one empty launch.
+__global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, const int2* __restrict__ in, int2* __restrict__ out, int level) {
+    const int n_in = (int)B.level_cnt[level];
+    for (int idx = blockIdx.x * PTB_BLOCK + threadIdx.x; idx < n_in; idx += gridDim.x * PTB_BLOCK) {
     const int2 item = in[idx];
     const int rec_base = 4 * (B.n - 1);
     const int wide_base = rec_base + 4 * B.n;
@@ -347,11 +350,12 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, con
         } else {
             const int slot = (int)atomicAdd(&B.stats[0], 1u);
             link[k] = wide_base + 4 * slot;
-            out[atomicAdd(&B.stats[1], 1u)] = make_int2(ref[k], slot);
+            out[atomicAdd(&B.level_cnt[level + 1], 1u)] = make_int2(ref[k], slot);
         }
     }
     float d[16];
     pt_encode_wide_node(cb, cnt, link, d);
     float4* dst = B.items + (size_t)wide_base + 4 * (size_t)item.y;
     for (int k = 0; k < 4; k++) dst[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+    }
 }

@@ -400,6 +400,7 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     HIP_TRY(c, tmp.get(&B.nbox, 6 * (size_t)n));
     HIP_TRY(c, tmp.get(&B.arrive, (size_t)n));
     HIP_TRY(c, tmp.get(&B.stats, 4));
+    HIP_TRY(c, tmp.get(&B.level_cnt, 68));
     HIP_TRY(c, tmp.get(&B.frontier_a, (size_t)n));
     HIP_TRY(c, tmp.get(&B.frontier_b, (size_t)n));
     B.verts = d_verts;
@@ -422,6 +423,9 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     const unsigned int st0[4] = {1u, 0u, 0u, 0u};   // wide slot 0 is the root's
     HIP_TRY(c, hipMemcpyAsync(B.cbounds, cb0, sizeof cb0, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(B.stats, st0, sizeof st0, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(B.level_cnt, 0, 68 * sizeof(unsigned int), st));
+    const unsigned int one = 1u;
+    HIP_TRY(c, hipMemcpyAsync(B.level_cnt, &one, sizeof one, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(items, 0, n_items * 64, st));
     HIP_TRY(c, hipEventRecord(e0, st));
 
@@ -433,6 +437,7 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     char* cub_tmp = nullptr;
     HIP_TRY(c, tmp.get(&cub_tmp, cub_bytes));
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, B.key_in, B.key, B.val_in, B.val, n, 0, 63, st));
+    unsigned int n_levels_max = 64;
     hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_node_depth, grd, blk, 0, st, B);
     HIP_TRY(c, hipGetLastError());
@@ -442,33 +447,34 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
         HIP_TRY(c, hipStreamSynchronize(st));
         if (deepest + 1 > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
         for (unsigned int level = deepest + 1; level-- > 0;) hipLaunchKernelGGL(k_fit_level, grd, blk, 0, st, B, level);
+        n_levels_max = deepest + 1;
     }
     hipLaunchKernelGGL(k_depth, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_records, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_binary, grd, blk, 0, st, B);
     HIP_TRY(c, hipGetLastError());
-    // 4-wide collapse, one launch per level of the wide tree
+    // 4-wide collapse, one launch per level of the wide tree; frontier sizes stay on the device, so
+    // nothing is read back between levels (a wide level spans at least one binary level: `deepest + 1`
+    // launches cover every tree; the empty ones at the end cost a few microseconds each)
     const int2 root_item = make_int2(0, 0);
     HIP_TRY(c, hipMemcpyAsync(B.frontier_a, &root_item, sizeof root_item, hipMemcpyHostToDevice, st));
-    int n_in = 1;
-    uint32_t levels = 0;
-    int2 *fin = B.frontier_a, *fout = B.frontier_b;
-    while (n_in > 0) {
-        if (++levels > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
-        HIP_TRY(c, hipMemsetAsync(B.stats + 1, 0, sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_collapse, dim3((unsigned)((n_in + PTB_BLOCK - 1) / PTB_BLOCK)), blk, 0, st, B, fin, n_in, fout);
+    {
+        int2 *fin = B.frontier_a, *fout = B.frontier_b;
+        const unsigned cgrid = (unsigned)std::min<int>((n + PTB_BLOCK - 1) / PTB_BLOCK, 2048);
+        for (unsigned int level = 0; level <= n_levels_max; level++) {
+            hipLaunchKernelGGL(k_collapse, dim3(cgrid), blk, 0, st, B, fin, fout, (int)level);
+            std::swap(fin, fout);
+        }
         HIP_TRY(c, hipGetLastError());
-        unsigned int n_out = 0;
-        HIP_TRY(c, hipMemcpyAsync(&n_out, B.stats + 1, sizeof n_out, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        if (n_out > (unsigned)n) return fail(c, PT_ERR_DEVICE, "pt_build_bvh: frontier overflow");
-        n_in = (int)n_out;
-        std::swap(fin, fout);
     }
     HIP_TRY(c, hipEventRecord(e1, st));
-    unsigned int stats[4];
+    unsigned int stats[4], level_cnt[68];
     HIP_TRY(c, hipMemcpyAsync(stats, B.stats, sizeof stats, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(level_cnt, B.level_cnt, sizeof level_cnt, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
+    uint32_t levels = 0;
+    while (levels < 66 && level_cnt[levels] > 0) levels++;
+    if (level_cnt[std::min<unsigned int>(n_levels_max + 1, 67)] != 0) return fail(c, PT_ERR_DEVICE, "pt_build_bvh: wide collapse did not finish");
     HIP_TRY(c, hipEventElapsedTime(&c->build_ms, e0, e1));
     if (stats[3] > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
 
