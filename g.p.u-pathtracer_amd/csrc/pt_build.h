@@ -1,7 +1,7 @@
 // pt_build.h — BVH construction ON the device (pt_build_bvh): the step in front
 // of the hot path.  The reference builds on the host (SplitBVHBuilder.cpp, 1.7 s per 100 k
 // triangles) and so does host/pthost.cpp (SAH/SBVH, ~1.4 s for 800 k; here 1.8 ms); this is the fast
-// alternative for scenes that change: a linear BVH
+// alternative for scenes that change: Morton order, then PLOC clustering (default) or a linear BVH
 //   1. k_tri_bounds   triangle boxes + bounds of the box centres (ordered-int atomics)
 //   2. k_morton       63-bit Morton key of every centre (21 bits per axis)
 //   3. hipcub radix sort of (key, triangle)
@@ -231,6 +231,104 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_fit_level(const BuildArrays B, un
     }
 }
 
+__device__ __forceinline__ float ptb_area(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+
+// ---- PLOC (Meister & Bittner 2018), the better-quality alternative to steps 4-5 ------------------
+// Clusters start as the leaves in Morton order.  Every round each cluster looks PTB_PLOC_RADIUS places
+// to either side for the neighbour whose union with it has the smallest surface; pairs that chose
+// each other merge into a new inner node; the survivors are compacted in order.  Boxes are known at
+// merge time (no fit pass); node numbers are handed out from the top down so that the last merge —
+// the root — is node 0, where the walks expect it.  Subtrees are no longer contiguous in Morton
+// order, so every triangle is its own leaf (the cut rule is switched off: leaf_max 0).
+#ifndef PTB_PLOC_RADIUS
+#define PTB_PLOC_RADIUS 8
+#endif
+struct PlocArrays {
+    int* cl;            // [n_c] cluster = child reference (>= 0 inner node, < 0 ~leaf position)
+    int* cl_next;       // [n_c] compacted survivors of this round
+    float* cbox;        // [n_c][6] boxes of the clusters, gathered once per round
+    int* nn;            // [n_c] chosen neighbour
+    int* keep;          // [n_c] 1 = survives the round (itself or as the merged node)
+    int* pos;           // [n_c] exclusive prefix sum of keep
+    int* ref;           // [n_c] what the cluster is after the round
+    int n_c;
+};
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_gather(const BuildArrays B, const PlocArrays Q) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= Q.n_c) return;
+    float bx[6];
+    ptb_child_box(B, Q.cl[i], bx);
+    for (int a = 0; a < 6; a++) Q.cbox[6 * (size_t)i + a] = bx[a];
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_nn(const PlocArrays Q) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= Q.n_c) return;
+    float a[6];
+    for (int k = 0; k < 6; k++) a[k] = Q.cbox[6 * (size_t)i + k];
+    int best = -1;
+    float best_area = 3.402823466e+38f;
+    const int lo = max(0, i - PTB_PLOC_RADIUS), hi = min(Q.n_c - 1, i + PTB_PLOC_RADIUS);
+    for (int j = lo; j <= hi; j++) {
+        if (j == i) continue;
+        const float* b = Q.cbox + 6 * (size_t)j;
+        const float u[6] = {fminf(a[0], b[0]), fminf(a[1], b[1]), fminf(a[2], b[2]), fmaxf(a[3], b[3]), fmaxf(a[4], b[4]), fmaxf(a[5], b[5])};
+        const float ar = ptb_area(u);
+        if (ar < best_area) { best_area = ar; best = j; }   // ties: the smaller position (deterministic)
+    }
+    Q.nn[i] = best;
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_merge(const BuildArrays B, const PlocArrays Q) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= Q.n_c) return;
+    const int j = Q.nn[i];
+    int ref = Q.cl[i], keep = 1;
+    if (j >= 0 && Q.nn[j] == i) {
+        if (i < j) {
+            const int id = (B.n - 2) - (int)atomicAdd(&B.stats[1], 1u);   // the last merge of all gets 0: the root
+            B.left[id] = Q.cl[i];
+            B.right[id] = Q.cl[j];
+            float* dst = B.nbox + 6 * (size_t)id;
+            for (int k = 0; k < 3; k++) {
+                dst[k] = fminf(Q.cbox[6 * (size_t)i + k], Q.cbox[6 * (size_t)j + k]);
+                dst[3 + k] = fmaxf(Q.cbox[6 * (size_t)i + 3 + k], Q.cbox[6 * (size_t)j + 3 + k]);
+            }
+            ref = id;
+        } else {
+            keep = 0;
+        }
+    }
+    Q.ref[i] = ref;
+    Q.keep[i] = keep;
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_scatter(const PlocArrays Q) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= Q.n_c) return;
+    if (Q.keep[i]) Q.cl_next[Q.pos[i]] = Q.ref[i];
+}
+
+// parent links (and the empty key ranges that switch the leaf cut off) once the tree is complete
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_parents(const BuildArrays B) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= B.n - 1) return;
+    const int cl = B.left[i], cr = B.right[i];
+    if (cl >= 0) B.parent_i[cl] = i; else B.parent_l[~cl] = i;
+    if (cr >= 0) B.parent_i[cr] = i; else B.parent_l[~cr] = i;
+    if (i == 0) B.parent_i[0] = -1;
+    B.first[i] = 0; B.last[i] = 0;
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_init(const BuildArrays B, const PlocArrays Q) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i < B.n) Q.cl[i] = ~i;
+}
+
 // depth of every leaf (edges to the root), for the stack bound
 __global__ void __launch_bounds__(PTB_BLOCK) k_depth(const BuildArrays B) {
     const int j = blockIdx.x * PTB_BLOCK + threadIdx.x;
@@ -294,11 +392,6 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_binary(const BuildArrays B) {
     d[14] = 0.f; d[15] = 0.f;
     float4* dst = B.items + 4 * (size_t)i;
     for (int k = 0; k < 4; k++) dst[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
-}
-
-__device__ __forceinline__ float ptb_area(const float* b) {
-    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
-    return 2.f * (dx * dy + dy * dz + dz * dx);
 }
 
 // One level of the 4-wide tree: every frontier entry (inner node, wide slot) adopts up to four

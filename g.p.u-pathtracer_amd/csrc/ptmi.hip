@@ -74,6 +74,7 @@ struct pt_ctx {
     size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 36;
+    int opt_build_algo = 1;      // pt_build_bvh: 0 LBVH (Karras), 1 PLOC (PT_OPT_BUILD_ALGO)
     int opt_sph_lds = 1;         // persistent kernel: sphere attributes from an LDS copy (PT_OPT_SPHERE_LDS)
     int opt_roles_batch = 16;    // role-split kernel: finished lanes that make a tracer wave leave the walk
     float4* d_roles_state = nullptr;   // role-split kernel: cold path state of every block's slots
@@ -220,6 +221,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             c->opt_walk = value;
             return PT_OK;
         case PT_OPT_SPHERE_LDS: c->opt_sph_lds = value != 0; return PT_OK;
+        case PT_OPT_BUILD_ALGO:
+            if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: build algorithm must be 0 (LBVH) or 1 (PLOC)");
+            c->opt_build_algo = value;
+            return PT_OK;
         case PT_OPT_ROLES_BATCH:
             if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: roles batch must be 1..64");
             c->opt_roles_batch = value;
@@ -356,8 +361,20 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
 }
 
 // ---- pt_build_bvh: the BVH built on the device (pt_build.h) ---------------------------------
+static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep);
+
 int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris) {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
+    bool too_deep = false;
+    int rc = build_bvh_impl(c, verts, n_verts, tris, n_tris, c->opt_build_algo, &too_deep);
+    // PLOC on degenerate input (hundreds of identical boxes: one merge per round, a chain): the Karras
+    // hierarchy separates equal keys by position and stays balanced
+    if (rc != PT_OK && too_deep && c->opt_build_algo == 1) rc = build_bvh_impl(c, verts, n_verts, tris, n_tris, 0, &too_deep);
+    return rc;
+}
+
+static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep) {
+    *too_deep = false;
     if (!verts || !tris || n_verts == 0 || n_tris == 0) return fail(c, PT_ERR_INVALID, "pt_build_bvh: empty mesh or null array");
     if (n_tris > (1u << 27) || n_verts > (1u << 30)) return fail(c, PT_ERR_INVALID, "pt_build_bvh: mesh too large for 32-bit links");
     if (c->opt_tri_test == 1) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: Woop records are made by the host path only (pt_upload_bvh)");
@@ -438,6 +455,53 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     HIP_TRY(c, tmp.get(&cub_tmp, cub_bytes));
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, B.key_in, B.key, B.val_in, B.val, n, 0, 63, st));
     unsigned int n_levels_max = 64;
+    const bool ploc = algo == 1 && n > 2;
+    if (ploc) {
+        // PLOC: rounds of nearest-neighbour search + mutual merges + ordered compaction
+        B.leaf_max = 0;   // every triangle its own leaf (subtrees are not contiguous in Morton order)
+        PlocArrays Q;
+        std::memset(&Q, 0, sizeof Q);
+        HIP_TRY(c, tmp.get(&Q.cl, (size_t)n));
+        HIP_TRY(c, tmp.get(&Q.cl_next, (size_t)n));
+        HIP_TRY(c, tmp.get(&Q.cbox, 6 * (size_t)n));
+        HIP_TRY(c, tmp.get(&Q.nn, (size_t)n));
+        HIP_TRY(c, tmp.get(&Q.keep, (size_t)n));
+        HIP_TRY(c, tmp.get(&Q.pos, (size_t)n + 1));
+        HIP_TRY(c, tmp.get(&Q.ref, (size_t)n));
+        size_t scan_bytes = 0;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, Q.keep, Q.pos, n, st));
+        char* scan_tmp = nullptr;
+        HIP_TRY(c, tmp.get(&scan_tmp, scan_bytes));
+        Q.n_c = n;
+        hipLaunchKernelGGL(k_ploc_init, grd, blk, 0, st, B, Q);
+        HIP_TRY(c, hipMemsetAsync(B.stats + 1, 0, sizeof(unsigned int), st));
+        int rounds = 0;
+        while (Q.n_c > 1) {
+            if (++rounds > 192) { *too_deep = true; return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: PLOC needs too many rounds (degenerate input)"); }
+            const dim3 g((unsigned)((Q.n_c + PTB_BLOCK - 1) / PTB_BLOCK));
+            hipLaunchKernelGGL(k_ploc_gather, g, blk, 0, st, B, Q);
+            hipLaunchKernelGGL(k_ploc_nn, g, blk, 0, st, Q);
+            hipLaunchKernelGGL(k_ploc_merge, g, blk, 0, st, B, Q);
+            HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, Q.keep, Q.pos, Q.n_c, st));
+            hipLaunchKernelGGL(k_ploc_scatter, g, blk, 0, st, Q);
+            HIP_TRY(c, hipGetLastError());
+            int last_pos = 0, last_keep = 0;
+            HIP_TRY(c, hipMemcpyAsync(&last_pos, Q.pos + (Q.n_c - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipMemcpyAsync(&last_keep, Q.keep + (Q.n_c - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            const int next = last_pos + last_keep;
+            if (next >= Q.n_c || next < 1) return fail(c, PT_ERR_DEVICE, "pt_build_bvh: PLOC round made no progress");
+            Q.n_c = next;
+            std::swap(Q.cl, Q.cl_next);
+        }
+        hipLaunchKernelGGL(k_ploc_parents, grd, blk, 0, st, B);
+        hipLaunchKernelGGL(k_node_depth, grd, blk, 0, st, B);
+        unsigned int deepest = 0;
+        HIP_TRY(c, hipMemcpyAsync(&deepest, B.stats + 3, sizeof deepest, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (deepest + 1 > 64) { *too_deep = true; return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: PLOC tree deeper than 64 levels"); }
+        n_levels_max = deepest + 1;
+    } else {
     hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_node_depth, grd, blk, 0, st, B);
     HIP_TRY(c, hipGetLastError());
@@ -448,6 +512,7 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
         if (deepest + 1 > 64) return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: tree deeper than 64 levels (degenerate input); use the host builder");
         for (unsigned int level = deepest + 1; level-- > 0;) hipLaunchKernelGGL(k_fit_level, grd, blk, 0, st, B, level);
         n_levels_max = deepest + 1;
+    }
     }
     hipLaunchKernelGGL(k_depth, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_records, grd, blk, 0, st, B);

@@ -47,11 +47,12 @@ def test_device_tree_hits_equal_brute_force(name):
     mesh = g.scene_mesh(name)
     t = g.PathTracer(0)
     try:
-        for leaf_max in (1, 2, 4):
+        for algo, leaf_max in ((0, 1), (0, 2), (0, 4), (1, 2)):     # LBVH with three leaf sizes, PLOC (the default)
+            t.set_option(g.OPT_BUILD_ALGO, algo)
             t.set_option(g.OPT_LEAF_MAX, leaf_max)
             ms = t.build_bvh(mesh)
             info = t.scene_info()
-            print(f"{name} leaf_max {leaf_max}: built in {ms:.2f} ms on the device, {info}")
+            print(f"{name} algo {algo} leaf_max {leaf_max}: built in {ms:.2f} ms on the device, {info}")
             assert info["n_tri_refs"] == mesh.n_tris and info["n_inner"] == mesh.n_tris - 1
             assert info["n_leaves"] >= mesh.n_tris / leaf_max and info["max_depth"] <= 64
             n = 20000 if name == "dragon" else 60000
@@ -89,6 +90,41 @@ def test_device_tree_image_equals_oracle(pt, scene, W, H, spp):
     assert n_diff <= pt.max_diff
     if n_diff == 0:
         assert np.array_equal(r, rref)
+
+
+@pytest.mark.parametrize("name", ["cornell", "bunny_low", "dragon"])
+def test_ploc_tree_hits_equal_brute_force(name):
+    """PT_OPT_BUILD_ALGO 1 (PLOC): same invariant — the closest hit does not depend on the tree."""
+    mesh = g.scene_mesh(name)
+    t = g.PathTracer(0)
+    try:
+        t.set_option(g.OPT_BUILD_ALGO, 1)
+        ms = t.build_bvh(mesh)
+        info = t.scene_info()
+        print(f"{name}: PLOC built in {ms:.2f} ms on the device, {info}")
+        assert info["n_tri_refs"] == mesh.n_tris and info["n_leaves"] == mesh.n_tris and info["max_depth"] <= 64
+        rays = random_rays(mesh, 30000, 3)
+        for cull in (True, False):
+            tg, ig, ng = gpu_trace(t, rays, cull)
+            tb, ib, nb = orc.trace_brute(mesh, rays, cull)
+            assert np.array_equal(ig, ib) and np.array_equal(tg, tb)
+            hit = ib >= 0
+            assert np.array_equal(ng[hit], nb[hit])
+        # and a rendered frame against the oracle over the host tree
+        W, H = 320, 200
+        cam, p = g.default_camera(W, H), g.default_params(W, H)
+        sph = g.reference_spheres()
+        ref, _, _ = orc.render(g.Bvh(mesh), sph, cam, p, 2)
+        t.upload_spheres(sph)
+        acc, rgba = t.alloc_frame(W, H)
+        t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 2)
+        t.sync()
+        a = acc.download(np.float32, (H, W, 3))
+        acc.free()
+        rgba.free()
+        assert int(np.any(a != ref, axis=-1).sum()) <= 2
+    finally:
+        t.close()
 
 
 def test_degenerate_inputs():

@@ -33,7 +33,10 @@ pt.set_option(g.OPT_LEAF_MAX, a.leaf_max)
 if "PT_SPH_LDS" in os.environ:
     pt.set_option(g.OPT_SPHERE_LDS, int(os.environ["PT_SPH_LDS"]))
 if a.device_build:
-    print("device build ms", pt.build_bvh(g.scene_mesh(a.scene)))
+    if "PT_BUILD_ALGO" in os.environ:
+        pt.set_option(g.OPT_BUILD_ALGO, int(os.environ["PT_BUILD_ALGO"]))
+    m_ = g.scene_mesh(a.scene)
+    print("device build ms", [round(pt.build_bvh(m_), 2) for _ in range(3)])
 else:
     bvh = g.Bvh(g.scene_mesh(a.scene), **kw)
     print("bvh", kw, bvh.stats)
