@@ -324,6 +324,42 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_ploc_parents(const BuildArrays B)
     B.first[i] = 0; B.last[i] = 0;
 }
 
+// Depth-first leaf order for a PLOC tree, so that every subtree covers a contiguous range of records
+// again and small subtrees can be cut into multi-triangle leaves like the LBVH's:
+//   k_ploc_size   (deepest level first)  size[node] = leaves below it, kept in `last`
+//   k_ploc_first  (root level first)     first[node]; a leaf child gets its new position
+//   k_ploc_reorder                       triangle ids move to the new positions, leaf references follow
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_size(const BuildArrays B, unsigned int level) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= B.n - 1 || B.arrive[i] != level) return;
+    const int cl = B.left[i], cr = B.right[i];
+    B.last[i] = (cl >= 0 ? B.last[cl] : 1) + (cr >= 0 ? B.last[cr] : 1);
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_first(const BuildArrays B, unsigned int level, int* __restrict__ newpos) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i >= B.n - 1 || B.arrive[i] != level) return;
+    const int f = level == 0 ? 0 : B.first[i];
+    if (level == 0) B.first[i] = 0;
+    const int cl = B.left[i], cr = B.right[i];
+    const int nl = cl >= 0 ? B.last[cl] : 1;
+    if (cl >= 0) B.first[cl] = f; else newpos[~cl] = f;
+    if (cr >= 0) B.first[cr] = f + nl; else newpos[~cr] = f + nl;
+}
+
+__global__ void __launch_bounds__(PTB_BLOCK) k_ploc_reorder(const BuildArrays B, const int* __restrict__ newpos, const int* __restrict__ val_old) {
+    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
+    if (i < B.n) {
+        B.val[newpos[i]] = val_old[i];
+    }
+    if (i < B.n - 1) {
+        const int cl = B.left[i], cr = B.right[i];
+        if (cl < 0) { B.left[i] = ~newpos[~cl]; B.parent_l[newpos[~cl]] = i; }
+        if (cr < 0) { B.right[i] = ~newpos[~cr]; B.parent_l[newpos[~cr]] = i; }
+        B.last[i] = B.first[i] + B.last[i] - 1;   // size -> last position
+    }
+}
+
 __global__ void __launch_bounds__(PTB_BLOCK) k_ploc_init(const BuildArrays B, const PlocArrays Q) {
     const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
     if (i < B.n) Q.cl[i] = ~i;

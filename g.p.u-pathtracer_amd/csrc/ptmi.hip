@@ -458,7 +458,6 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
     const bool ploc = algo == 1 && n > 2;
     if (ploc) {
         // PLOC: rounds of nearest-neighbour search + mutual merges + ordered compaction
-        B.leaf_max = 0;   // every triangle its own leaf (subtrees are not contiguous in Morton order)
         PlocArrays Q;
         std::memset(&Q, 0, sizeof Q);
         HIP_TRY(c, tmp.get(&Q.cl, (size_t)n));
@@ -501,6 +500,16 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
         HIP_TRY(c, hipStreamSynchronize(st));
         if (deepest + 1 > 64) { *too_deep = true; return fail(c, PT_ERR_UNSUPPORTED, "pt_build_bvh: PLOC tree deeper than 64 levels"); }
         n_levels_max = deepest + 1;
+        // depth-first leaf order: subtrees become contiguous record ranges, so small ones can be cut into
+        // multi-triangle leaves (PT_OPT_LEAF_MAX) exactly as in the LBVH
+        B.leaf_max = std::max(1, c->opt_leaf_max ? c->opt_leaf_max : 1);
+        int* newpos = nullptr;
+        HIP_TRY(c, tmp.get(&newpos, (size_t)n));
+        for (unsigned int level = deepest + 1; level-- > 0;) hipLaunchKernelGGL(k_ploc_size, grd, blk, 0, st, B, level);
+        for (unsigned int level = 0; level <= deepest; level++) hipLaunchKernelGGL(k_ploc_first, grd, blk, 0, st, B, level, newpos);
+        HIP_TRY(c, hipMemcpyAsync(B.val_in, B.val, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_ploc_reorder, grd, blk, 0, st, B, newpos, B.val_in);
+        HIP_TRY(c, hipGetLastError());
     } else {
     hipLaunchKernelGGL(k_hierarchy, grd, blk, 0, st, B);
     hipLaunchKernelGGL(k_node_depth, grd, blk, 0, st, B);

@@ -102,7 +102,7 @@ def test_ploc_tree_hits_equal_brute_force(name):
         ms = t.build_bvh(mesh)
         info = t.scene_info()
         print(f"{name}: PLOC built in {ms:.2f} ms on the device, {info}")
-        assert info["n_tri_refs"] == mesh.n_tris and info["n_leaves"] == mesh.n_tris and info["max_depth"] <= 64
+        assert info["n_tri_refs"] == mesh.n_tris and mesh.n_tris / 2 <= info["n_leaves"] <= mesh.n_tris and info["max_depth"] <= 64
         rays = random_rays(mesh, 30000, 3)
         for cull in (True, False):
             tg, ig, ng = gpu_trace(t, rays, cull)
