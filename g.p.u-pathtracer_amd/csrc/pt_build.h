@@ -31,6 +31,7 @@ struct BuildArrays {
     const int* tris;         // [n][3]
     int n;                   // triangles (>= 2)
     int n_orig;              // caller's triangle count (1 when the lone triangle was doubled to get a tree)
+    const int* id_map;       // optional: triangle id reported for row t (NULL = t itself)
     int leaf_max;            // subtree size that becomes one leaf (>= 1)
     // per triangle (unsorted): box
     float* tbox;             // [n][6] lo xyz, hi xyz
@@ -403,7 +404,8 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_records(const BuildArrays B) {
         v2[a] = B.verts[3 * (size_t)i2 + a];
     }
     if (v0[0] == 0.f) v0[0] = 0.f;   // -0.0f -> +0.0f, as the Compact producer stores it (host/pthost.cpp)
-    pt_encode_record(v0, v1, v2, min(t, B.n_orig - 1), last, rec);
+    const int row = min(t, B.n_orig - 1);
+    pt_encode_record(v0, v1, v2, B.id_map ? B.id_map[row] : row, last, rec);
     float4* dst = B.items + 4 * (size_t)(B.n - 1) + 4 * (size_t)j;
     for (int k = 0; k < 4; k++) dst[k] = make_float4(rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]);
 }

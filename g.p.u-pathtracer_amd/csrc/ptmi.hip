@@ -74,6 +74,7 @@ struct pt_ctx {
     size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 36;
+    int opt_rebuild = 0;         // pt_upload_bvh: 1 = re-cluster the uploaded triangles on the device (PT_OPT_REBUILD)
     int opt_build_algo = 1;      // pt_build_bvh: 0 LBVH (Karras), 1 PLOC (PT_OPT_BUILD_ALGO)
     int opt_sph_lds = 1;         // persistent kernel: sphere attributes from an LDS copy (PT_OPT_SPHERE_LDS)
     int opt_roles_batch = 16;    // role-split kernel: finished lanes that make a tracer wave leave the walk
@@ -221,6 +222,7 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             c->opt_walk = value;
             return PT_OK;
         case PT_OPT_SPHERE_LDS: c->opt_sph_lds = value != 0; return PT_OK;
+        case PT_OPT_REBUILD: c->opt_rebuild = value != 0; return PT_OK;
         case PT_OPT_BUILD_ALGO:
             if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: build algorithm must be 0 (LBVH) or 1 (PLOC)");
             c->opt_build_algo = value;
@@ -299,6 +301,9 @@ int pt_upload(pt_ctx* c, void* dst, const void* src, size_t bytes) {
     return PT_OK;
 }
 
+static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep,
+                          const int32_t* id_map = nullptr);
+
 // ---------------------------------------------------------------------------------------
 // Scene upload: validate the reference Compact arrays (CudaBVH.cpp:121-270), then re-lay
 // them out for the gfx950 kernels:
@@ -325,6 +330,32 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     for (const ptscene::Ref& r : T.refs) max_id = std::max(max_id, r.id);
     if (c->d_tri_matid && (size_t)max_id >= c->n_tri_matid)
         return fail(c, PT_ERR_INVALID, "pt_upload_bvh: the triangle-material array on this context does not cover this BVH's triangle ids (clear or re-upload it first)");
+    if (c->opt_rebuild && c->opt_tri_test == 0) {
+        // PT_OPT_REBUILD: keep the caller's TRIANGLES, not its hierarchy — the distinct triangles of the
+        // Compact arrays (a spatial-split builder lists some more than once, each time in full) are
+        // clustered again on the device (pt_build.h).  The closest hit does not depend on the tree, so the
+        // images are the same bit for bit; whether the new tree is faster depends on the scene.
+        std::vector<int32_t> ids;
+        std::vector<float> verts;
+        {
+            std::vector<const ptscene::Ref*> sorted;
+            sorted.reserve(T.refs.size());
+            for (const ptscene::Ref& r : T.refs) sorted.push_back(&r);
+            std::sort(sorted.begin(), sorted.end(), [](const ptscene::Ref* a, const ptscene::Ref* b) { return a->id < b->id; });
+            for (const ptscene::Ref* r : sorted) {
+                if (!ids.empty() && ids.back() == r->id) continue;
+                ids.push_back(r->id);
+                verts.insert(verts.end(), r->v, r->v + 9);
+            }
+        }
+        std::vector<int32_t> tri_rows(3 * ids.size());
+        for (size_t i = 0; i < tri_rows.size(); i++) tri_rows[i] = (int32_t)i;
+        bool too_deep = false;
+        int rc = build_bvh_impl(c, verts.data(), verts.size() / 3, tri_rows.data(), ids.size(), c->opt_build_algo, &too_deep, ids.data());
+        if (rc != PT_OK && too_deep && c->opt_build_algo == 1)
+            rc = build_bvh_impl(c, verts.data(), verts.size() / 3, tri_rows.data(), ids.size(), 0, &too_deep, ids.data());
+        return rc;
+    }
     ptscene::refine(T, (uint32_t)c->opt_leaf_max);
     ptscene::Output O;
     ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
@@ -361,8 +392,6 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
 }
 
 // ---- pt_build_bvh: the BVH built on the device (pt_build.h) ---------------------------------
-static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep);
-
 int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris) {
     if (!c) return fail(nullptr, PT_ERR_INVALID, "null ctx");
     bool too_deep = false;
@@ -373,7 +402,8 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     return rc;
 }
 
-static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep) {
+static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep,
+                          const int32_t* id_map) {
     *too_deep = false;
     if (!verts || !tris || n_verts == 0 || n_tris == 0) return fail(c, PT_ERR_INVALID, "pt_build_bvh: empty mesh or null array");
     if (n_tris > (1u << 27) || n_verts > (1u << 30)) return fail(c, PT_ERR_INVALID, "pt_build_bvh: mesh too large for 32-bit links");
@@ -422,6 +452,12 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
     HIP_TRY(c, tmp.get(&B.frontier_b, (size_t)n));
     B.verts = d_verts;
     B.tris = d_tris_idx;
+    if (id_map) {
+        int* d_map = nullptr;
+        HIP_TRY(c, tmp.get(&d_map, n_tris));
+        HIP_TRY(c, hipMemcpyAsync(d_map, id_map, n_tris * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        B.id_map = d_map;
+    }
     const size_t n_items = (size_t)(n - 1) + (size_t)n + (size_t)(n - 1);   // binary, records, wide (upper bound)
     if (n_items * 4 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_build_bvh: scene too large for 32-bit links");
     float4* items = nullptr;
@@ -568,6 +604,7 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
     c->max_depth = stats[3];
     c->scene_bytes = n_items * 64;
     c->max_tri_id = (int32_t)n_tris - 1;
+    if (id_map) for (size_t i = 0; i < n_tris; i++) c->max_tri_id = std::max(c->max_tri_id, id_map[i]);
     c->has_bvh = true;
     return PT_OK;
 }

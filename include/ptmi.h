@@ -117,6 +117,9 @@ enum {
                                  a tree as good as the host SAH/SBVH builder's, ~6.5 ms for 800 k triangles;
                                  degenerate input falls back to 0), 0 = LBVH (Karras hierarchy: 1.8 ms, a
                                  tree that traces ~14 % slower)                                    */
+    PT_OPT_REBUILD = 17,      /* pt_upload_bvh: 1 = keep the uploaded TRIANGLES but build the hierarchy again on
+                                 the device (PT_OPT_BUILD_ALGO); same images bit for bit; faster or slower
+                                 than the caller's tree depending on the scene; default 0             */
     PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
                                  for Moller-Trumbore, what the reference kernel runs
                                  (cudaUtils.h:135-172; default, bit-exact vs the oracle);

@@ -190,3 +190,35 @@ def test_device_build_800k_speed_and_parity():
         assert n_diff <= 40
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("scene", ["cornell", "gto_sixteen", "cornell_dragon"])
+def test_upload_with_rebuild_is_bit_identical(pt, scene):
+    """PT_OPT_REBUILD: pt_upload_bvh keeps the triangles of the Compact arrays (SBVH duplicates folded,
+    original ids kept) and clusters them again on the device; the frame equals the plain upload's."""
+    mesh = g.scene_mesh(scene)
+    bvh = g.Bvh(mesh)                       # spatial splits on: gto_sixteen lists 63 % of its triangles more than once
+    W, H = 400, 225
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.frame = 9
+    sph = g.reference_spheres()
+    ref, _, _ = orc.render(bvh, sph, cam, p, 2)
+    frames = []
+    for rebuild in (0, 1):
+        pt.set_option(g.OPT_REBUILD, rebuild)
+        try:
+            pt.upload_bvh(bvh)
+        finally:
+            pt.set_option(g.OPT_REBUILD, 0)
+        info = pt.scene_info()
+        pt.upload_spheres(sph)
+        acc, rgba = pt.alloc_frame(W, H)
+        pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, 2)
+        pt.sync()
+        frames.append(acc.download(np.float32, (H, W, 3)))
+        acc.free()
+        rgba.free()
+        if rebuild:
+            assert info["n_tri_refs"] == mesh.n_tris          # duplicates folded
+    assert int(np.any(frames[0] != ref, axis=-1).sum()) <= pt.max_diff
+    assert int(np.any(frames[1] != ref, axis=-1).sum()) <= pt.max_diff
