@@ -12,7 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=40)
 a = ap.parse_args()
 rng = np.random.default_rng(1)
-scenes = {n: g.Bvh(g.scene_mesh(n)) for n in ("cornell", "gto_sixteen", "cornell_dragon")}
+meshes = {n: g.scene_mesh(n) for n in ("cornell", "gto_sixteen", "cornell_dragon")}
+scenes = {n: g.Bvh(m) for n, m in meshes.items()}
 pts = {}
 for name, kern in (("persistent", g.KERNEL_PERSISTENT), ("role-split", g.KERNEL_WAVEFRONT), ("mega", g.KERNEL_MEGA_BVH2)):
     pts[name] = g.PathTracer(0)
@@ -31,8 +32,17 @@ for r in range(a.rounds):
     cam = g.default_camera(max(W, 61), max(H, 61))
     cam.aspect = W / H
     res = {}
+    source = ["host tree", "host tree, rebuilt on the device", "device PLOC", "device LBVH"][int(rng.integers(0, 4))]
     for name, pt in pts.items():
-        pt.upload_bvh(scenes[scene])
+        # the reference kernel (persistent) always walks the host tree; the others a randomly chosen tree
+        src = "host tree" if name == "persistent" else source
+        if src == "host tree":
+            pt.upload_bvh(scenes[scene])
+        elif src == "host tree, rebuilt on the device":
+            pt.set_option(g.OPT_REBUILD, 1); pt.upload_bvh(scenes[scene]); pt.set_option(g.OPT_REBUILD, 0)
+        else:
+            pt.set_option(g.OPT_BUILD_ALGO, 1 if src == "device PLOC" else 0)
+            pt.build_bvh(meshes[scene])
         pt.upload_spheres(g.reference_spheres() if spheres else None)
         acc, rgba = pt.alloc_frame(W, H + 64)
         for f in range(3):
@@ -44,8 +54,11 @@ for r in range(a.rounds):
         pt.sync()
         res[name] = acc.download(np.float32, (H, W, 3))
         acc.free(); rgba.free()
-    ok = all(np.array_equal(res["persistent"], v, equal_nan=True) for v in res.values())
-    print(f"round {r}: {scene} {W}x{H} spp {spp} mat {mat} spheres {spheres} depth {depth} part {part}/{parts}: {'same' if ok else 'DIFFERENT'}", flush=True)
+    # another tree may let a grazing candidate through the quantised boxes that the first one culls: <= 2 pixels
+    nd = max(int(np.any((res["persistent"] != v) & ~(np.isnan(res["persistent"]) & np.isnan(v)), axis=-1).sum()) for v in res.values())
+    ok = nd <= (0 if source == "host tree" else 2)
+    print(f"round {r}: {scene} {W}x{H} spp {spp} mat {mat} spheres {spheres} depth {depth} part {part}/{parts}, others on {source}: "
+          f"{'same' if nd == 0 else str(nd) + ' pixels differ'}", flush=True)
     if not ok:
         sys.exit(1)
 print(f"{n_launch} launches in {time.time() - t0:.1f} s: all kernels agree")
