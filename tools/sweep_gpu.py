@@ -40,6 +40,8 @@ if a.device_build:
 else:
     bvh = g.Bvh(g.scene_mesh(a.scene), **kw)
     print("bvh", kw, bvh.stats)
+    if "PT_REBUILD" in os.environ:
+        pt.set_option(g.OPT_REBUILD, int(os.environ["PT_REBUILD"]))
     pt.upload_bvh(bvh)
 print("leaf_max", a.leaf_max, pt.scene_info())
 pt.upload_spheres(None if a.no_spheres else g.reference_spheres())
