@@ -290,8 +290,11 @@ def main():
         n_x = max(5, a.steps // 5)
         step(0)
         dtx, _ = timed(n_x, 1)
-        extra["device_bvh_build_ms"] = round(build_ms, 2)
+        extra["device_bvh_build_ms"] = round(build_ms, 2)          # PLOC (the default PT_OPT_BUILD_ALGO)
         extra["mrays_per_s_device_built_tree"] = round(W * H * a.depth * a.spp * n_x / dtx / 1e6, 1)
+        pt.set_option(g.OPT_BUILD_ALGO, 0)                          # Karras LBVH: the fastest build
+        extra["device_bvh_build_ms_lbvh"] = round(min(pt.build_bvh(mesh) for _ in range(3)), 2)
+        pt.set_option(g.OPT_BUILD_ALGO, 1)
         info = info_host
 
     merged_ok = None
