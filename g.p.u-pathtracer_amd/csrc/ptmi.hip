@@ -74,6 +74,7 @@ struct pt_ctx {
     size_t samples_bytes = 0;
     int n_cu = 0;
     int opt_batch = 36;
+    int opt_presplit = 0;        // pt_build_bvh: 0 off, else the target length in per cent of diag/sqrt(n) (PT_OPT_PRESPLIT)
     int opt_rebuild = 0;         // pt_upload_bvh: 1 = re-cluster the uploaded triangles on the device (PT_OPT_REBUILD)
     int opt_build_algo = 1;      // pt_build_bvh: 0 LBVH (Karras), 1 PLOC (PT_OPT_BUILD_ALGO)
     int opt_sph_lds = 1;         // persistent kernel: sphere attributes from an LDS copy (PT_OPT_SPHERE_LDS)
@@ -223,6 +224,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             return PT_OK;
         case PT_OPT_SPHERE_LDS: c->opt_sph_lds = value != 0; return PT_OK;
         case PT_OPT_REBUILD: c->opt_rebuild = value != 0; return PT_OK;
+        case PT_OPT_PRESPLIT:
+            if (value < 0 || value > 100000) return fail(c, PT_ERR_INVALID, "pt_set_option: presplit must be 0 (off) .. 100000 (per cent of diag/sqrt(n))");
+            c->opt_presplit = value;
+            return PT_OK;
         case PT_OPT_BUILD_ALGO:
             if (value != 0 && value != 1) return fail(c, PT_ERR_INVALID, "pt_set_option: build algorithm must be 0 (LBVH) or 1 (PLOC)");
             c->opt_build_algo = value;
@@ -417,7 +422,7 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
 
     // a lone triangle is doubled: the hierarchy needs two leaves (both report id 0)
     std::vector<int32_t> two;
-    const int n = (int)std::max<size_t>(n_tris, 2);
+    int n = (int)std::max<size_t>(n_tris, 2);
     if (n_tris == 1) { two.assign(tris, tris + 3); two.insert(two.end(), tris, tris + 3); tris = two.data(); }
 
     HIP_TRY(c, hipSetDevice(c->device));
@@ -425,14 +430,54 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
     DevTemp tmp;
     BuildArrays B;
     std::memset(&B, 0, sizeof B);
-    B.n = n;
     B.n_orig = (int)n_tris;
     B.leaf_max = std::max(1, c->opt_leaf_max ? c->opt_leaf_max : 1);
+    hipStream_t st = c->stream;
     float* d_verts = nullptr;
     int* d_tris_idx = nullptr;
     HIP_TRY(c, tmp.get(&d_verts, 3 * n_verts));
     HIP_TRY(c, tmp.get(&d_tris_idx, 3 * (size_t)n));
-    HIP_TRY(c, tmp.get(&B.tbox, 6 * (size_t)n));
+    HIP_TRY(c, hipMemcpyAsync(d_verts, verts, 3 * n_verts * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(d_tris_idx, tris, 3 * (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
+    HIP_TRY(c, hipEventRecord(e0, st));
+    if (c->opt_presplit && n_tris >= 64) {
+        // pre-splitting: long triangles enter as several primitives (pt_build.h); the target length is a
+        // multiple of the edge a triangle would have if the n of them tiled a square of the scene's diagonal
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (size_t i = 0; i < 3 * n_verts; i++) { lo[i % 3] = std::min(lo[i % 3], verts[i]); hi[i % 3] = std::max(hi[i % 3], verts[i]); }
+        const float diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+        const float target = 0.01f * (float)c->opt_presplit * diag / std::sqrt((float)n_tris);
+        int *d_cnt = nullptr, *d_off = nullptr;
+        HIP_TRY(c, tmp.get(&d_cnt, n_tris));
+        HIP_TRY(c, tmp.get(&d_off, n_tris));
+        const dim3 g0((unsigned)((n_tris + PTB_BLOCK - 1) / PTB_BLOCK));
+        hipLaunchKernelGGL(k_split_count, g0, dim3(PTB_BLOCK), 0, st, d_verts, d_tris_idx, (int)n_tris, target, d_cnt);
+        size_t sb = 0;
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, sb, d_cnt, d_off, (int)n_tris, st));
+        char* stmp = nullptr;
+        HIP_TRY(c, tmp.get(&stmp, sb));
+        HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(stmp, sb, d_cnt, d_off, (int)n_tris, st));
+        int last_off = 0, last_cnt = 0;
+        HIP_TRY(c, hipMemcpyAsync(&last_off, d_off + (n_tris - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(&last_cnt, d_cnt + (n_tris - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const long n_ref = (long)last_off + last_cnt;
+        if (n_ref > (long)n_tris && n_ref < (1l << 27)) {
+            int* d_ref = nullptr;
+            HIP_TRY(c, tmp.get(&B.tbox, 6 * (size_t)n_ref));
+            HIP_TRY(c, tmp.get(&d_ref, (size_t)n_ref));
+            hipLaunchKernelGGL(k_split_emit, g0, dim3(PTB_BLOCK), 0, st, d_verts, d_tris_idx, (int)n_tris, target, d_off, B.tbox, d_ref);
+            HIP_TRY(c, hipGetLastError());
+            B.ref_tri = d_ref;
+            n = (int)n_ref;
+        }
+    }
+    B.n = n;
+    if (!B.tbox) HIP_TRY(c, tmp.get(&B.tbox, 6 * (size_t)n));
     HIP_TRY(c, tmp.get(&B.cbounds, 6));
     HIP_TRY(c, tmp.get(&B.key_in, (size_t)n));
     HIP_TRY(c, tmp.get(&B.key, (size_t)n));
@@ -465,13 +510,6 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
     B.items = items;
     struct ItemsGuard { float4* p; ~ItemsGuard() { if (p) (void)hipFree(p); } } guard{items};
 
-    hipStream_t st = c->stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(c, hipEventCreate(&e0));
-    HIP_TRY(c, hipEventCreate(&e1));
-    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
-    HIP_TRY(c, hipMemcpyAsync(d_verts, verts, 3 * n_verts * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(d_tris_idx, tris, 3 * (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     const unsigned int cb0[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     const unsigned int st0[4] = {1u, 0u, 0u, 0u};   // wide slot 0 is the root's
     HIP_TRY(c, hipMemcpyAsync(B.cbounds, cb0, sizeof cb0, hipMemcpyHostToDevice, st));
@@ -480,7 +518,6 @@ static int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const i
     const unsigned int one = 1u;
     HIP_TRY(c, hipMemcpyAsync(B.level_cnt, &one, sizeof one, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(items, 0, n_items * 64, st));
-    HIP_TRY(c, hipEventRecord(e0, st));
 
     const dim3 blk(PTB_BLOCK), grd((unsigned)((n + PTB_BLOCK - 1) / PTB_BLOCK));
     hipLaunchKernelGGL(k_tri_bounds, grd, blk, 0, st, B);

@@ -120,6 +120,9 @@ enum {
     PT_OPT_REBUILD = 17,      /* pt_upload_bvh: 1 = keep the uploaded TRIANGLES but build the hierarchy again on
                                  the device (PT_OPT_BUILD_ALGO); same images bit for bit; faster or slower
                                  than the caller's tree depending on the scene; default 0             */
+    PT_OPT_PRESPLIT = 18,     /* pt_build_bvh / PT_OPT_REBUILD: 0 (default) = off; v > 0 = triangles longer than
+                                 v per cent of (scene diagonal / sqrt(n triangles)) enter the builder as up
+                                 to 8 primitives, one per slab of their box (early split clipping)      */
     PT_OPT_TRI_TEST = 10,     /* triangle records built at the next pt_upload_bvh: 0 = v0/e1/e2
                                  for Moller-Trumbore, what the reference kernel runs
                                  (cudaUtils.h:135-172; default, bit-exact vs the oracle);

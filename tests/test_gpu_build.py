@@ -127,6 +127,31 @@ def test_ploc_tree_hits_equal_brute_force(name):
         t.close()
 
 
+@pytest.mark.parametrize("name,presplit", [("gto_sixteen", 200), ("cornell_dragon", 200), ("bunny_low", 50)])
+def test_presplit_tree_hits_equal_brute_force(name, presplit):
+    """PT_OPT_PRESPLIT: long triangles enter the builder as several primitives (slabs of their box);
+    hits, ids and normals must not change."""
+    mesh = g.scene_mesh(name)
+    t = g.PathTracer(0)
+    try:
+        for algo in (1, 0):
+            t.set_option(g.OPT_BUILD_ALGO, algo)
+            t.set_option(g.OPT_PRESPLIT, presplit)
+            ms = t.build_bvh(mesh)
+            info = t.scene_info()
+            print(f"{name} algo {algo} presplit {presplit}: {ms:.2f} ms, {info}")
+            assert info["n_tri_refs"] > mesh.n_tris          # something was split
+            rays = random_rays(mesh, 40000, 11)
+            for cull in (True, False):
+                tg, ig, ng = gpu_trace(t, rays, cull)
+                tb, ib, nb = orc.trace_brute(mesh, rays, cull)
+                assert np.array_equal(ig, ib) and np.array_equal(tg, tb)
+                hit = ib >= 0
+                assert np.array_equal(ng[hit], nb[hit])
+    finally:
+        t.close()
+
+
 def test_degenerate_inputs():
     t = g.PathTracer(0)
     try:

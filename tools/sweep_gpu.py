@@ -32,6 +32,8 @@ pt = g.PathTracer(0)
 pt.set_option(g.OPT_LEAF_MAX, a.leaf_max)
 if "PT_SPH_LDS" in os.environ:
     pt.set_option(g.OPT_SPHERE_LDS, int(os.environ["PT_SPH_LDS"]))
+if "PT_PRESPLIT" in os.environ:
+    pt.set_option(g.OPT_PRESPLIT, int(os.environ["PT_PRESPLIT"]))
 if a.device_build:
     if "PT_BUILD_ALGO" in os.environ:
         pt.set_option(g.OPT_BUILD_ALGO, int(os.environ["PT_BUILD_ALGO"]))
