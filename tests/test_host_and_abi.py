@@ -214,3 +214,15 @@ def test_product_never_touches_the_oracle():
     for so in (g._abi.PTMI_PATH, g._abi.PTHOST_PATH):
         ldd = subprocess.check_output(["ldd", so]).decode()
         assert "liborc" not in ldd
+
+
+def test_bench_and_entry_points_parse():
+    """bench.py / __graft_entry__.py / tools: no syntax errors, the CLI answers --help without a GPU."""
+    import ast
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ["bench.py", "__graft_entry__.py"] + [os.path.join("tools", f) for f in sorted(os.listdir(os.path.join(root, "tools"))) if f.endswith(".py")]:
+        ast.parse(open(os.path.join(root, rel)).read(), rel)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
