@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the path-tracing hot path on MI355X.
 
-Metric (BASELINE.json): Mrays/s (+ achieved algorithmic GB/s vs the HBM roofline),
+Metric (BASELINE.json): Mrays/s (+ achieved GB/s against the memory roofline),
 cornell_dragon 1920x1080, depth 4, reference sphere room, 1/2/4/8 GPUs.
 
   python bench.py --gpus N --steps K --warmup W
@@ -12,21 +12,24 @@ A "step" is one progressive frame: one pass of the hot path — ONE pt_render ca
 ABI, `render(accum, bvh, camera, spp)` of BASELINE.json — folding `--spp` samples per pixel
 (default 16; BASELINE's config 5 uses 8) into the whole 1920x1080 framebuffer.  The reference
 launches one sample per displayed frame (BasicScene.cpp:404); a call with spp = S equals S such
-launches bit for bit, but traces the S samples as independent work items, which is what gives
-eight GPUs enough parallel work on an eighth of the frame each (1 spp: 0.47 ms for an eighth of
-a 1.13 ms frame; 8 spp: 1.29 of 7.10 ms).  With N > 1 the framebuffer is
+launches bit for bit, but traces the S samples as independent work items (the 1-spp-per-call rate
+is reported beside the headline as `mrays_per_s_1spp`).  With N > 1 the framebuffer is
 tile-split into interleaved 8-row stripes (stripe s belongs to rank s % N), every rank
 renders its stripes of the SAME frame with the scene replicated, and the display words are
 gathered on rank 0 with RCCL each step (the reference copies the frame to the display
 every frame too, BasicScene.cpp:424-432).  Total work is fixed => "scaling": "strong".
+`--gpus N` without a torchrun environment starts the N ranks itself, as child processes.
 
-Rank 0 prints ONE JSON line.  Everything under oracle/ is used here only for the
-`cpu_baseline` leg and for the algorithmic-byte counters of the roofline (checker, never
-the thing measured).
+Rank 0 prints ONE JSON line.  Everything under oracle/ is used here only AFTER the timed region:
+for the `cpu_baseline` leg, for the parity check of the timed configuration against it, and for
+the algorithmic-byte counters of the roofline (checker, never the thing measured).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -40,6 +43,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_NAMES = {0: "auto", 1: "mega", 3: "persistent", 5: "wavefront"}
 
 
 def parse():
@@ -55,23 +59,35 @@ def parse():
                     help="samples per pixel folded by ONE pt_render call = one step (render(accum, bvh, camera, spp))")
     ap.add_argument("--mat", default="diff", choices=["diff", "metal", "spec", "refr"])
     ap.add_argument("--no-spheres", action="store_true")
-    ap.add_argument("--kernel", type=int, default=0, help="PT_KERNEL_* (0 = auto)")
+    ap.add_argument("--kernel", type=int, default=0, help="PT_KERNEL_* (0 = auto, 1 mega, 3 persistent, 5 wavefront)")
     ap.add_argument("--occ", type=int, default=0, help="PT_OPT_OCCUPANCY (0 = library default)")
     ap.add_argument("--lds-stack", type=int, default=-1, help="PT_OPT_LDS_STACK (-1 = library default)")
     ap.add_argument("--top", type=int, default=-1, help="PT_OPT_TOP_NODES (-1 = library default)")
+    ap.add_argument("--batch", type=int, default=0, help="PT_OPT_BATCH / PT_OPT_WAVE_BATCH (0 = library default)")
     ap.add_argument("--stripe-rows", type=int, default=8)
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="steps of the workload run on the CPU oracle: baseline + parity (0 = skip)")
     ap.add_argument("--no-cpu-reference", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the metal/spec side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (materials, 1 spp, device tree, big scene, gather bound)")
+    ap.add_argument("--device-build", action="store_true", help="build the BVH on the device (pt_build_bvh) instead of the host SBVH builder")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dry run on a ONE-GPU box: every rank uses cuda:0, gloo backend, stripes gathered "
                          "through host memory (validates the multi-rank code path, not its speed)")
     return ap.parse_args()
 
 
+def source_sha():
+    """Identifies the kernel sources a profile was taken with (profiles/*_pmc_traffic.json is only quoted
+    when it was collected for THIS code)."""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "g.p.u-pathtracer_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "ptmi.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(g, bvh, sph, cam, params, first_frame, n_frames, spp):
-    """The oracle (kind 'port') timed on this host's cores over `n_frames` frames of the SAME
-    workload; also yields the N_* counters that define the algorithmic bytes per frame."""
+    """The oracle (kind 'port') timed on this host's cores over `n_frames` steps of the SAME workload,
+    starting from an empty accumulator; also yields the N_* counters that define the algorithmic bytes,
+    and the accumulator for the parity check."""
     import orc
     p = g.Params.from_buffer_copy(params)
     p.part_count, p.part_index = 1, 0
@@ -121,12 +137,39 @@ def cpu_reference_tracer(g):
                       f"room + dragon (100k tris), {W}x{H}, {spp} spp, {r['segments']} segments in {r['seconds']:.2f} s"}
 
 
+def gather_bound(table_bytes):
+    """Random 64-byte dependent gathers from a table of the scene's size, 8 waves/SIMD, every lane busy:
+    the rate the memory hierarchy serves ITEMS at for this working set (tools/ubench_gather.hip), measured
+    by a CHILD process (its own HIP context; nothing is exec'ed from this one)."""
+    exe = os.path.join(ROOT, "tools", "ubench_gather")
+    if not os.path.exists(exe):
+        return None
+    n_items = max(1024, int(table_bytes // 64))
+    out = subprocess.run([exe, "--json", str(n_items), "256"], capture_output=True, text=True, timeout=120)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return json.loads(line[-1]) if out.returncode == 0 and line else None
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as children (fresh
+    processes, before anything here has touched the GPU) and pass rank 0's JSON line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -149,7 +192,7 @@ def main():
     W, H = a.width, a.height
     mat = {"diff": g.MAT_DIFF, "metal": g.MAT_METAL, "spec": g.MAT_SPEC, "refr": g.MAT_REFR}[a.mat]
     mesh = g.scene_mesh(a.scene)
-    bvh = g.Bvh(mesh)
+    bvh = None if a.device_build else g.Bvh(mesh)
     sph = None if a.no_spheres else g.reference_spheres()
     n_sph = 0 if sph is None else len(sph)
     cam = g.default_camera(W, H)
@@ -171,7 +214,13 @@ def main():
         pt.set_option(g.OPT_LDS_STACK, a.lds_stack)
     if a.top >= 0:
         pt.set_option(g.OPT_TOP_NODES, a.top)
-    pt.upload_bvh(bvh)
+    if a.batch:
+        pt.set_option(g.OPT_BATCH, a.batch)
+        pt.set_option(g.OPT_WAVE_BATCH, a.batch)
+    if a.device_build:
+        pt.build_bvh(mesh)
+    else:
+        pt.upload_bvh(bvh)
     pt.upload_spheres(sph)
     info = pt.scene_info()
 
@@ -193,7 +242,7 @@ def main():
     ev_gather = [None] * n_buf
     step_no = [0]
 
-    def step(i, params=base, spp=a.spp, fresh=False):
+    def step(i, params=base, spp=a.spp, fresh=False, into=None):
         p = g.Params.from_buffer_copy(params)
         p.frame, p.sample_index = i * spp, 1 if fresh else 1 + i * spp
         k = step_no[0] % n_buf
@@ -201,7 +250,7 @@ def main():
         buf = rgbas[k]
         if overlap and ev_gather[k] is not None:
             stream.wait_event(ev_gather[k])          # the gather that last read this buffer is done
-        pt.launch_kernel(accum.data_ptr(), buf.data_ptr(), cam, p, spp)
+        pt.launch_kernel((accum if into is None else into).data_ptr(), buf.data_ptr(), cam, p, spp)
         if world == 1:
             return
         if overlap:
@@ -228,16 +277,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_steps, first, params=base, events=False):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)] if events else None
+    def timed(n_steps, first, params=base, spp=a.spp, fresh=False):
         barrier()
         t0 = time.perf_counter()
         for k in range(n_steps):
-            if ev:
-                ev[k][0].record()
-            step(first + k, params)
-            if ev:
-                ev[k][1].record()
+            step(first + k, params, spp=spp, fresh=fresh)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -246,56 +290,70 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        kms = [e0.elapsed_time(e1) for e0, e1 in ev] if ev else None
-        return dt, kms
+        return dt
 
+    # ------------------------------------------------------------------ the timed region
     for k in range(a.warmup):
         step(k)
-    dt, kernel_ms = timed(a.steps, a.warmup, events=True)
+    dt = timed(a.steps, a.warmup)
 
-    # exact segment count of the timed frames: replay them instrumented (untimed)
+    # ---- everything below is outside the timed region ------------------------------------------
+    # device time by stage (HIP events recorded by the library on the launch stream, PT_OPT_TIMING)
+    pt.set_option(g.OPT_TIMING, 1)
+    stage = {}
+    n_tm = min(a.steps, 8)
+    for k in range(n_tm):
+        step(a.warmup + k)
+        torch.cuda.synchronize()
+        for name, ms in pt.stage_ms().items():
+            stage[name] = stage.get(name, 0.0) + ms / n_tm
+    pt.set_option(g.OPT_TIMING, 0)
+
+    # exact segment / item counts of the timed frames: replay them instrumented
     pt.set_option(g.OPT_COUNTERS, 1)
-    seg = torch.zeros(2, dtype=torch.float64, device="cpu" if a.rehearse else dev)
-    n_count = min(a.steps, 4)
+    seg = torch.zeros(6, dtype=torch.float64, device="cpu" if a.rehearse else dev)
+    n_count = min(a.steps, 2)
+    wstats = None
     for k in range(n_count):
         step(a.warmup + k)
         torch.cuda.synchronize()
         c = pt.counters()
-        seg[0] += c["rays"]
-        seg[1] += c["paths"]
+        for j, key in enumerate(("rays", "paths", "inner", "tris", "leaves", "hits")):
+            seg[j] += c[key]
+        wstats = pt.wave_stats()
     pt.set_option(g.OPT_COUNTERS, 0)
     if world > 1:
         dist.all_reduce(seg)
-    rays_per_step = float(seg[0].item()) / n_count
+    rays_per_step, paths_per_step, items_nodes, items_recs = (float(seg[j].item()) / n_count for j in (0, 1, 2, 3))
     closed = abs(rays_per_step - W * H * a.depth * a.spp) < 0.5
     total_rays = rays_per_step * a.steps
 
+    def rate(n_steps, seconds, spp=a.spp):
+        return round(rays_per_step / a.spp * spp * n_steps / seconds / 1e6, 1)
+
     extra = {}
     if not a.no_extra:
+        n_x = max(5, a.steps // 5)
         for name, m in (("metal", g.MAT_METAL), ("spec", g.MAT_SPEC)):
             if m == mat:
                 continue
             pm = g.Params.from_buffer_copy(base)
             pm.tri_mat = m
-            n_x = max(5, a.steps // 5)
             step(0, pm)
-            dtx, _ = timed(n_x, 1, pm)
-            extra[f"mrays_per_s_{name}"] = round(W * H * a.depth * a.spp * n_x / dtx / 1e6, 1)
-
-    if not a.no_extra and world == 1:
-        # side measurement (SURVEY §8 f1): the same workload over a tree built ON the device
-        # (pt_build_bvh, LBVH); done last, it replaces the scene of this context
-        info_host = pt.scene_info()
-        build_ms = min(pt.build_bvh(mesh) for _ in range(3))
-        n_x = max(5, a.steps // 5)
-        step(0)
-        dtx, _ = timed(n_x, 1)
-        extra["device_bvh_build_ms"] = round(build_ms, 2)          # PLOC (the default PT_OPT_BUILD_ALGO)
-        extra["mrays_per_s_device_built_tree"] = round(W * H * a.depth * a.spp * n_x / dtx / 1e6, 1)
-        pt.set_option(g.OPT_BUILD_ALGO, 0)                          # Karras LBVH: the fastest build
-        extra["device_bvh_build_ms_lbvh"] = round(min(pt.build_bvh(mesh) for _ in range(3)), 2)
-        pt.set_option(g.OPT_BUILD_ALGO, 1)
-        info = info_host
+            extra[f"mrays_per_s_{name}"] = round(W * H * a.depth * a.spp * n_x / timed(n_x, 1, pm) / 1e6, 1)
+        # the reference's own granularity: ONE sample per launch (BasicScene.cpp:395-404), sync between launches
+        # not needed (in-order stream)
+        step(0, spp=1)
+        n_1 = max(20, a.steps)
+        extra["mrays_per_s_1spp"] = rate(n_1, timed(n_1, 1, spp=1), spp=1)
+        if world == 1:
+            for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT)):
+                pt.set_option(g.OPT_KERNEL, kern)
+                step(0)
+                extra[f"mrays_per_s_{kname}"] = rate(n_x, timed(n_x, 1))
+                step(0, spp=1)
+                extra[f"mrays_per_s_1spp_{kname}"] = rate(n_1, timed(n_1, 1, spp=1), spp=1)
+            pt.set_option(g.OPT_KERNEL, a.kernel)
 
     merged_ok = None
     if world > 1:
@@ -312,59 +370,170 @@ def main():
             pt.launch_kernel(acc2.data_ptr(), rgba2.data_ptr(), cam, solo, a.spp)
             torch.cuda.synchronize()
             merged_ok = bool(torch.equal(last_frame()[:H], rgba2[:H]))
+
     if rank == 0:
         value = total_rays / dt / 1e6
         out = {
-            "metric": "Mrays/sec, cornell_dragon 1920x1080 (+ achieved algorithmic GB/s vs HBM roofline)",
+            "metric": "Mrays/sec, cornell_dragon 1920x1080 (+ achieved GB/s against the memory roofline)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if a.rehearse else ""),
             "config": {"workload": f"{a.scene} ({mesh.n_tris} tris) {W}x{H} depth {a.depth} {a.mat} + "
                                    f"{'reference 8-sphere room' if n_sph else 'no spheres'}, {a.spp} spp per step",
+                       "kernel": KERNEL_NAMES.get(a.kernel, str(a.kernel)),
                        "bvh": {"inner": info["n_inner"], "tri_refs": info["n_tri_refs"], "max_depth": info["max_depth"],
-                               "device_mb": round(info["device_bytes"] / 2 ** 20, 1)},
+                               "device_mb": round(info["device_bytes"] / 2 ** 20, 1), "built_on": "device" if a.device_build else "host"},
                        "parallelism": (f"tile-split x{world} ({rows}-row stripes, RCCL all-gather of RGBA8 every step"
                                        f"{', overlapped with the next render' if overlap else ''})") if world > 1 else "1 GPU",
                        "closed_scene": bool(closed), "rays_per_step": rays_per_step,
                        "tile_split_equals_single_gpu": merged_ok},
+            "stage_ms": {k: round(v, 4) for k, v in stage.items() if v > 0},
         }
         out.update(extra)
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
-        if world == 1:
-            kavg = float(np.mean(kernel_ms))
-            roof["kernel"] = "k_trace_persist_bvh2" if a.kernel in (0, 3) else "k_trace_mega_bvh2"
-            roof["kernel_ms_avg"] = round(kavg, 4)
-            if a.cpu_frames > 0:
-                cb, cnt, _ = cpu_baseline(g, bvh, sph, cam, base, a.warmup * a.spp, a.cpu_frames, a.spp)
-                out["cpu_baseline"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in cb.items()}
-                alg = g.algorithmic_bytes(cnt, n_sph) / a.cpu_frames      # bytes per step
-                roof["achieved"] = round(alg / (kavg * 1e-3) / 1e9, 1)
-                roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
-                roof["algorithmic_bytes_per_step"] = int(alg)
-                roof["bytes_per_ray"] = round(alg / (cnt["rays"] / a.cpu_frames), 1)
-                roof["nodes_per_ray"] = round(cnt["inner"] / cnt["rays"], 2)
-                roof["tris_per_ray"] = round(cnt["tris"] / cnt["rays"], 2)
-            # PMC traffic cannot be collected inside this process: it is the committed figure of the
-            # rocprofv3 --pmc passes over THIS command (tools/profile_gpu.sh), valid for the default workload
-            tr = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            default_workload = (a.scene, W, H, a.depth, a.spp, a.mat, a.no_spheres) == ("cornell_dragon_800k", 1920, 1080, 4, 16, "diff", False)
-            if os.path.exists(tr) and default_workload:
+        # ---------------------------------------------------------------- roofline of the dominant kernel
+        # units: one launch of the dominant kernel.  PT_KERNEL_WAVEFRONT launches k_wf_extend once per bounce
+        # (`depth` launches per step); the other frame kernels are one launch per step.
+        dom = max((k for k in ("frame", "extend", "shade") if stage.get(k, 0) > 0), key=lambda k: stage[k], default=None)
+        launches = a.depth if dom in ("extend", "shade") else 1
+        kname = {"frame": "k_trace_persist_bvh2" if a.kernel != 1 else "k_trace_mega_bvh2", "extend": "k_wf_extend", "shade": "k_wf_shade"}.get(dom)
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": kname, "launches_per_step": launches}
+        if world == 1 and dom:
+            kms = stage[dom] / launches
+            roof["kernel_ms_avg"] = round(kms, 4)
+            # (1) what the kernel REQUESTS from the memory system per launch: 64-byte items (node or record) the walk
+            #     fetches, counted by the instrumented replay, + its streams (wavefront: 32-B ray in, 8-B hit out;
+            #     persistent: 12 B sample colour out per path)
+            items = (items_nodes + items_recs) / launches
+            stream_b = (rays_per_step * 40.0 / launches) if dom == "extend" else (12.0 * paths_per_step)
+            req = items * 64.0 + stream_b
+            roof["requested"] = {"bytes_per_launch": int(req), "gbs": round(req / (kms * 1e-3) / 1e9, 1),
+                                 "items_per_ray": round((items_nodes + items_recs) / rays_per_step, 2),
+                                 "gitems_per_s": round(items / (kms * 1e-3) / 1e9, 2),
+                                 "note": "64 B x (wide nodes + triangle records fetched) + the kernel's own streams; served by L2 / "
+                                         "Infinity Cache when the scene fits them"}
+            if wstats:
+                roof["lane_use"] = {"node_steps": round(wstats["act_node"] / max(1, 64 * wstats["it_node"]), 3),
+                                    "record_steps": round(wstats["act_rec"] / max(1, 64 * wstats["it_rec"]), 3),
+                                    "stack_overflows_per_ray": round(wstats["stack_overflows"] / max(1.0, rays_per_step), 4)}
+            # (2) the bound that CAN bind it: dependent random 64-byte gathers over a table of the scene's size
+            if not a.no_extra:
                 try:
-                    roof["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+                    gb = gather_bound(info["device_bytes"])
+                except Exception as e:
+                    gb = {"error": str(e)[:100]}
+                if gb and "items_per_s" in gb:
+                    roof["gather_bound"] = {"gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
+                                            "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
+                                            "table_mb": round(gb["table_bytes"] / 2 ** 20, 1),
+                                            "frac": round(items / (kms * 1e-3) / gb["items_per_s_l2_resident"], 4),
+                                            "note": "tools/ubench_gather (child process): every lane of 8 waves/SIMD chases random 64-B items; "
+                                                    "l2_resident (2 MB table: every fetch an L2 hit) is the ceiling of ANY per-lane walk, "
+                                                    "uniform_over_scene is a walk with no locality at all; frac = this kernel's item rate / the ceiling"}
+            # (3) HBM-side traffic per launch from rocprofv3 --pmc passes: only quoted when collected for THIS source
+            tr = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(tr):
+                try:
+                    j = json.load(open(tr))
+                    w = j.get("workloads", {}).get(f"{a.scene}/{KERNEL_NAMES.get(a.kernel, a.kernel)}/{a.spp}spp")
+                    if j.get("source_sha") == source_sha() and w and w.get("kernel") == kname:
+                        roof["traffic"] = w.get("hbm_bytes_per_launch")
+                        roof["traffic_source"] = "profiles/r02_pmc_traffic.json (same kernel sources)"
                 except Exception:
                     pass
-            roof["note"] = ("frac > 1 is not a measurement error: 'achieved' counts ALGORITHMIC bytes (SURVEY 8d: 64 B per node "
-                            "visited, 48 B per triangle tested, ...), which the L2 / Infinity Cache serve; 'traffic' is what "
-                            "crossed the L2<->fabric boundary per launch. The kernel is bound by the random 64-byte gather rate "
-                            "of the cache hierarchy and by divergent VALU issue, not by HBM (DESIGN.md 5, 7).")
-            if not a.no_cpu_reference:
-                try:
-                    ref = cpu_reference_tracer(g)
-                    if ref:
-                        out["cpu_reference_tracer"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ref.items()}
-                except Exception as e:  # a baseline, never a reason to lose the GPU number
-                    out["cpu_reference_tracer"] = {"error": str(e)[:200]}
+        if world == 1 and a.cpu_frames > 0:
+            cb, cnt, ref_acc = cpu_baseline(g, bvh if bvh is not None else g.Bvh(mesh), sph, cam, base, a.warmup * a.spp, a.cpu_frames, a.spp)
+            out["cpu_baseline"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in cb.items()}
+            # parity of the TIMED configuration: the same first steps on the GPU, empty accumulator, vs the oracle
+            acc_chk = torch.zeros_like(accum)
+            for k in range(a.cpu_frames):
+                pp = g.Params.from_buffer_copy(base)
+                pp.frame, pp.sample_index = (a.warmup + k) * a.spp, 1 + k * a.spp
+                pt.launch_kernel(acc_chk.data_ptr(), rgba.data_ptr(), cam, pp, a.spp)
+            torch.cuda.synchronize()
+            got = acc_chk[:H].cpu().numpy()
+            diff = got.astype(np.float64) - ref_acc
+            out["parity"] = {"l2": float(np.sqrt(np.mean(np.sum(diff ** 2, axis=-1)))),
+                             "n_diff": int(np.any(got != ref_acc, axis=-1).sum()), "pixels": W * H,
+                             "max_abs": float(np.abs(diff).max()),
+                             "what": f"GPU accumulator after {a.cpu_frames} timed-configuration step(s) vs oracle/pt_oracle.c, same seeds"}
+            if dom:
+                # SURVEY 8(d) ALGORITHMIC bytes (reference layout: 64 B per binary node, 48 B per triangle, 16 B per
+                # leaf, 4 B per hit, 44 B per sphere, 28 B per pixel-sample), counted by the oracle on the reference's
+                # own Compact arrays.  The walk part is priced against the walk kernel, everything against the step.
+                alg_step = g.algorithmic_bytes(cnt, n_sph) / a.cpu_frames
+                alg_walk = (64 * cnt["inner"] + 48 * cnt["tris"] + 16 * cnt["leaves"] + 4 * cnt["hits"]) / a.cpu_frames
+                step_ms = sum(v for k, v in stage.items() if k != "none")
+                alg_launch = (alg_walk if dom == "extend" else alg_step) / launches
+                roof["achieved"] = round(alg_launch / (stage[dom] / launches * 1e-3) / 1e9, 1)
+                roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
+                roof["algorithmic"] = {"bytes_per_launch": int(alg_launch), "bytes_per_step": int(alg_step),
+                                       "bytes_per_ray": round(alg_step / (cnt["rays"] / a.cpu_frames), 1),
+                                       "nodes_per_ray": round(cnt["inner"] / cnt["rays"], 2), "tris_per_ray": round(cnt["tris"] / cnt["rays"], 2),
+                                       "gbs_whole_step": round(alg_step / (step_ms * 1e-3) / 1e9, 1)}
+                roof["note"] = ("achieved/frac follow SURVEY 8d: ALGORITHMIC bytes of the reference layout per launch of the dominant "
+                                "kernel / its HIP-event duration / 8 TB/s.  The 105 MB scene sits in L2 + Infinity Cache, so this figure is "
+                                "not bounded by HBM (frac may exceed 1); 'requested' is what this kernel really fetches, 'gather_bound.frac' "
+                                "(<= 1) prices it against the measured gather rate of the cache hierarchy, 'traffic' is the measured "
+                                "HBM-side bytes when a PMC profile of these sources is committed; big_scene repeats it beyond the Infinity Cache.")
         out["roofline"] = roof
+        if world == 1 and not a.no_cpu_reference:
+            try:
+                ref = cpu_reference_tracer(g)
+                if ref:
+                    out["cpu_reference_tracer"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ref.items()}
+            except Exception as e:  # a baseline, never a reason to lose the GPU number
+                out["cpu_reference_tracer"] = {"error": str(e)[:200]}
+
+    if not a.no_extra and world == 1:
+        # side measurement (SURVEY §8 f1): the same workload over a tree built ON the device
+        # (pt_build_bvh); done last, it replaces the scene of this context
+        n_x = max(5, a.steps // 5)
+        build_ms = min(pt.build_bvh(mesh) for _ in range(3))
+        step(0)
+        out["device_bvh_build_ms"] = round(build_ms, 2)          # PLOC (the default PT_OPT_BUILD_ALGO)
+        out["mrays_per_s_device_built_tree"] = rate(n_x, timed(n_x, 1))
+        pt.set_option(g.OPT_BUILD_ALGO, 0)                          # Karras LBVH: the fastest build
+        out["device_bvh_build_ms_lbvh"] = round(min(pt.build_bvh(mesh) for _ in range(3)), 2)
+        pt.set_option(g.OPT_BUILD_ALGO, 1)
+        # EXTRA workload beyond the Infinity Cache (SURVEY §7 hard parts): cornell + 64 dragon copies, item buffer
+        # ~0.8 GB > 256 MiB, tree built on the device; same camera / room / spp.  Not the headline.
+        try:
+            big = g.scene_mesh("cornell_dragon_6400k")
+            b_ms = pt.build_bvh(big)
+            binfo = pt.scene_info()
+            step(0)
+            n_b = max(3, a.steps // 10)
+            dtb = timed(n_b, 1)
+            pt.set_option(g.OPT_TIMING, 1)
+            step(1)
+            torch.cuda.synchronize()
+            bst = pt.stage_ms()
+            pt.set_option(g.OPT_TIMING, 0)
+            pt.set_option(g.OPT_COUNTERS, 1)
+            step(1)
+            torch.cuda.synchronize()
+            bc = pt.counters()
+            pt.set_option(g.OPT_COUNTERS, 0)
+            bdom = max((k for k in ("frame", "extend") if bst.get(k, 0) > 0), key=lambda k: bst[k])
+            b_items = bc["inner"] + bc["tris"]
+            b_stream = bc["rays"] * 40.0 if bdom == "extend" else 12.0 * bc["paths"]
+            out["big_scene"] = {"workload": f"cornell_dragon_6400k ({big.n_tris} tris) {W}x{H} depth {a.depth} {a.mat} + sphere room, {a.spp} spp per step",
+                                "device_mb": round(binfo["device_bytes"] / 2 ** 20, 1), "device_build_ms": round(b_ms, 1),
+                                "mrays_per_s": round(bc["rays"] * n_b / dtb / 1e6, 1), "ms_per_step": round(dtb / n_b * 1e3, 3),
+                                "stage_ms": {k: round(v, 3) for k, v in bst.items() if v > 0},
+                                "items_per_ray": round(b_items / bc["rays"], 2),
+                                "requested_gbs": round((b_items * 64.0 + b_stream) / (bst[bdom] * 1e-3) / 1e9, 1),
+                                "hbm_frac_of_peak_if_all_missed": round((b_items * 64.0 + b_stream) / (bst[bdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            gb = gather_bound(binfo["device_bytes"])
+            if gb and "items_per_s" in gb:
+                out["big_scene"]["gather_bound"] = {"gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
+                                                    "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
+                                                    "frac": round(b_items / (bst[bdom] * 1e-3) / gb["items_per_s_l2_resident"], 4)}
+        except Exception as e:
+            out["big_scene"] = {"error": str(e)[:200]}
+
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

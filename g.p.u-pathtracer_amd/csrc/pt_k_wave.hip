@@ -1,0 +1,375 @@
+// pt_k_wave.hip — the stage-split ("wavefront") frame pipeline, PT_KERNEL_WAVEFRONT.
+// One translation unit of libptmi.so (pt_ctx.h).
+//
+// BASELINE.json configs[4] / SURVEY.md §7 step 5e: "ray buffers in SoA, extend / shade / generate
+// kernels, ballot + prefix-sum compaction of live rays between bounces".  The reference has nothing
+// like it (one thread per pixel, tracer.cu:413-414); the arithmetic of a path is the reference's
+// (path_begin / trav_run_wide / path_shade_hit are the functions the other frame kernels call), so the
+// images are the same bit for bit — only WHERE a path's state lives between segments differs:
+//
+//   generate   one lane per (sample, pixel) slot in tile order: camera ray -> ray record, sample colour = 0
+//   per bounce
+//     extend   persistent waves: a wave draws REGIONS of the ray queue from eight sharded counters,
+//              walks the BVH for 64 rays at a time and refills a lane as soon as its ray is done (its whole
+//              per-lane state is one ray + the walk: no path state, 8 waves per SIMD); writes (t, record)
+//     shade    one lane per live record, every wave full: spheres, shading, BRDF sample (tracer.cu:98-296);
+//              emitted light is added to the sample colour in place, a miss writes the background
+//              (tracer.cu:140-142), survivors are packed to the front of their region's next generation with
+//              a ballot + prefix count (v_mbcnt) — dead paths cost nothing in the next stage
+//   k_fold_samples folds the sample colours into the running mean (tracer.cu:386-391), as for every kernel.
+//
+// The path records stream through HBM (read once, written once per stage, 16-byte pieces, coalesced): this
+// is the part of the path loop that is bandwidth work, and the only per-ray state the latency-bound BVH walk
+// still carries is the ray itself.  Why it pays: in the persistent kernel a finished lane idles through other
+// lanes' node steps until 36 of 64 lanes want shading (node steps ran at 55 % lane use, shading passes of
+// ~700 instructions at 56 %, path starts at 20 %); here every stage runs one kind of work.
+#include "pt_ctx.h"
+
+// ------------------------------------------------------------------------------------------------
+// block-level compaction: exclusive rank of the calling lane among the block's lanes with keep == true,
+// and the block's total.  Four waves: ballot + v_mbcnt inside a wave, one LDS word per wave.
+__device__ __forceinline__ int wf_block_rank(bool keep, int& total, int* s_cnt) {
+    const unsigned long long m = __ballot(keep);
+    const int w = threadIdx.x >> 6;
+    const int in_wave = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if ((threadIdx.x & 63) == 0) s_cnt[w] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < PT_BLOCK / 64; k++) {
+        const int c = s_cnt[k];
+        if (k < w) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + in_wave;
+}
+
+// copies the first PT_KSPHERES spheres' attributes from the kernel arguments into LDS (path_shade's sph_tab = 0)
+__device__ __forceinline__ void wf_sphere_table() {
+    if (threadIdx.x < 11 * PT_KSPHERES) {
+        PT_KARGS(K);
+        const float v = ((const __attribute__((address_space(4))) float*)&K.ksph[0])[threadIdx.x];
+        ((float*)s_dyn)[threadIdx.x] = v;
+        if (threadIdx.x % 11 < 4) ((float*)s_dyn)[88 + 4 * (threadIdx.x / 11) + threadIdx.x % 11] = v;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// once per call: the frame hashes of the call's samples (uf::hash, utilfun.cpp:380-389) and fresh queue
+// counters for every bounce's extend launch
+__global__ void __launch_bounds__(256) k_wf_prepare(const KParams P) {
+    for (uint32_t i = threadIdx.x; i < P.spp; i += 256) P.wf.hashes[i] = pt_wang64(P.frame + i);
+    for (uint32_t i = threadIdx.x; i < P.wf.queues_words; i += 256) P.wf.queues_all[i] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate: slot = region * 256 + thread, in the tile order of the other frame kernels (slot >> 6 = work
+// tile = (sample, tile), slot & 63 = pixel of the 8x8 tile), so a wave's primary rays are coherent.
+__global__ void __launch_bounds__(PT_BLOCK) k_wf_generate(const KParams P) {
+    __shared__ int s_cnt[PT_BLOCK / 64];
+    const uint32_t slot = blockIdx.x * PT_REGION + threadIdx.x;
+    int wt = (int)(slot >> 6);
+    const uint32_t s_idx = (uint32_t)(wt / P.n_tiles);
+    wt -= (int)s_idx * P.n_tiles;
+    bool valid = s_idx < P.spp;
+    int tx = 0, ty = 0, px = 0, py = 0;
+    if (valid) valid = pt_tile_coords(P, wt, tx, ty);
+    if (valid) {
+        px = tx * PT_TILE + (int)(slot & 7u);
+        py = ty * PT_TILE + (int)((slot >> 3) & 7u);
+        valid = px < P.W && py < P.H;  // tracer.cu:358
+    }
+    PathState ps;
+    uint32_t pix = 0;
+    if (valid) {
+        pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
+        path_begin(P, px, py, (uint64_t)pix, P.frame + s_idx, ps);
+    }
+    int total;
+    const int r = wf_block_rank(valid, total, s_cnt);
+    if (valid) {
+        const size_t i = (size_t)blockIdx.x * PT_REGION + (size_t)r;
+        P.wf.ray0_out[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+        P.wf.ray1_out[i] = make_float4(ps.d.y, ps.d.z, __uint_as_float(pix), __uint_as_float((s_idx << 12) | ps.rng.n));
+        float* dst = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;   // accu = 0 (tracer.cu:48)
+    }
+    if (threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// extend: the closest-hit walk (rows a5-a7) over the ray queue; see the file header.
+template <bool COUNT, int OCC, int LSTK>
+__global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    TravOverflow<LSTK> stk_ovf;
+    TravStack<LSTK, PT_BLOCK> stk(__builtin_amdgcn_readfirstlane(tid & ~63), stk_ovf);
+    const bool cull = P.cull != 0;
+    const uint32_t n_regions = (uint32_t)P.wf.n_regions;
+    const uint32_t shard_regions = (n_regions + PT_SHARDS - 1) / PT_SHARDS;
+    const int batch = P.batch;
+
+    uint32_t next = 0, end = 0;   // wave-uniform: the part of the wave's region not handed to lanes yet
+    bool empty = false;           // wave-uniform: every shard of the queue is exhausted
+    int shard = (int)(blockIdx.x & (PT_SHARDS - 1));
+
+    bool live = false;
+    uint32_t idx = 0;
+    v3 o = V3(0.f, 0.f, 0.f), d = V3(0.f, 0.f, 0.f);
+    TravState ts;
+    ts.idx = ts.idy = ts.idz = ts.oodx = ts.oody = ts.oodz = 0.f;
+    ts.node = PT_SENTINEL; ts.leaf = 0; ts.sp = 0;
+    ts.h.t = PT_F32_MAX; ts.h.tri = -1; ts.h.rec = 0;
+    TravCount tc;
+    tc.inner = tc.tris = tc.leaves = 0;
+    tc.it_node = tc.act_node = tc.it_rec = tc.act_rec = 0;
+    uint32_t n_rays = 0, it_begin = 0, act_begin = 0, it_loop = 0;
+
+    for (;;) {
+        if (COUNT) it_loop++;
+        // ---- refill: idle lanes take the next records of the wave's region(s); lane -> record by a ballot +
+        // prefix count (v_mbcnt) of the idle mask
+        const unsigned long long idle = __ballot(!live);
+        const int n_idle = __popcll(idle);
+        if (!empty && (n_idle >= batch || n_idle == 64)) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            uint32_t served = 0;
+            for (int round = 0; round < 8 && served < (uint32_t)n_idle; round++) {
+                if (next == end) {
+                    // eight counters (blocks b and b + 8 share an XCD under round-robin placement: speed only);
+                    // shard s owns regions s, s + 8, ...; an empty shard is left for the next one
+                    bool got = false;
+                    for (int tries = 0; tries < PT_SHARDS && !got; tries++) {
+                        uint32_t k = 0;
+                        if (lane == 0) k = atomicAdd(P.wf.queue + shard * PT_SHARD_STRIDE, 1u);
+                        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                        const uint32_t r = k * PT_SHARDS + (uint32_t)shard;
+                        if (k < shard_regions && r < n_regions) {
+                            const int c = __builtin_amdgcn_readfirstlane(P.wf.cnt_in[r]);
+                            next = r * PT_REGION;
+                            end = next + (uint32_t)c;
+                            got = true;
+                        } else {
+                            shard = (shard + 1) & (PT_SHARDS - 1);
+                        }
+                    }
+                    if (!got) { empty = true; break; }
+                }
+                const uint32_t take = min((uint32_t)n_idle - served, end - next);
+                if (!live && rank >= served && rank < served + take) {
+                    idx = next + (rank - served);
+                    const float4 a = P.wf.ray0_in[idx], b = P.wf.ray1_in[idx];
+                    o = V3(a.x, a.y, a.z);
+                    d = V3(a.w, b.x, b.y);
+                    trav_begin(ts, o, d, stk, P.sc.wide_root);
+                    live = true;
+                }
+                next += take;
+                served += take;
+            }
+            if (COUNT && served) { it_begin++; act_begin += served; }
+        }
+        const unsigned long long busy = __ballot(live);
+        if (!busy) {
+            if (empty) break;
+            continue;
+        }
+        // ---- walk until `batch` lanes have finished (lanes that can get no more work do not count)
+        const int n_dead = empty ? 64 - __popcll(busy) : 0;
+        if (live) {
+            const bool fin = trav_run_wide<COUNT, true, false, false>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
+            if (fin) {
+                P.wf.hit[idx] = make_float2(ts.h.t, __int_as_float(ts.h.rec));
+                live = false;
+                if (COUNT) n_rays++;
+            }
+        }
+    }
+
+    if (COUNT) {
+        const uint32_t a = wave_sum_u32(n_rays), b = wave_sum_u32(tc.inner), c = wave_sum_u32(tc.tris), dd = wave_sum_u32(tc.leaves);
+        const uint32_t w_it_node = wave_sum_u32(tc.it_node), w_act_node = wave_sum_u32(tc.act_node);
+        const uint32_t w_it_rec = wave_sum_u32(tc.it_rec), w_act_rec = wave_sum_u32(tc.act_rec);
+        const uint32_t w_ovf = wave_sum_u32(stk.n_ovf);
+        if (lane == 0) {
+            atomicAdd(&P.counters[0], (unsigned long long)a);
+            atomicAdd(&P.counters[1], (unsigned long long)b);
+            atomicAdd(&P.counters[2], (unsigned long long)c);
+            atomicAdd(&P.counters[3], (unsigned long long)dd);
+            atomicAdd(&P.counters[6], (unsigned long long)w_it_node);
+            atomicAdd(&P.counters[7], (unsigned long long)w_act_node);
+            atomicAdd(&P.counters[8], (unsigned long long)w_it_rec);
+            atomicAdd(&P.counters[9], (unsigned long long)w_act_rec);
+            atomicAdd(&P.counters[12], (unsigned long long)it_begin);
+            atomicAdd(&P.counters[13], (unsigned long long)act_begin);
+            atomicAdd(&P.counters[14], (unsigned long long)it_loop);
+            atomicAdd(&P.counters[15], (unsigned long long)w_ovf);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shade: one bounce of tracer.cu:98-296 for every live record of a region; see the file header.
+template <bool COUNT>
+__global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
+    __shared__ int s_cnt[PT_BLOCK / 64];
+    wf_sphere_table();
+    const int n_in = P.wf.cnt_in[blockIdx.x];
+    const bool last = P.wf.bounce + 1 >= P.depth;
+    if (n_in == 0) {
+        if (!last && threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = 0;
+        return;
+    }
+    const bool have = (int)threadIdx.x < n_in;
+    const size_t i = (size_t)blockIdx.x * PT_REGION + threadIdx.x;
+    bool alive = false, tri_hit = false;
+    PathState ps;
+    uint32_t pix = 0, s_idx = 0;
+    if (have) {
+        const float4 a = P.wf.ray0_in[i], b = P.wf.ray1_in[i];
+        const float2 hh = P.wf.hit[i];
+        ps.o = V3(a.x, a.y, a.z);
+        ps.d = V3(a.w, b.x, b.y);
+        pix = __float_as_uint(b.z);
+        const uint32_t sn = __float_as_uint(b.w);
+        s_idx = sn >> 12;
+        ps.mask = V3(1.f, 1.f, 1.f);
+        if (P.wf.bounce > 0) ps.mask = V3(P.wf.mask_in[i], P.wf.mask_in[(size_t)P.wf.cap + i], P.wf.mask_in[2 * (size_t)P.wf.cap + i]);
+        ps.accu = V3(0.f, 0.f, 0.f);   // this segment's emission only: the running sum lives in the sample buffer
+        ps.depth = P.wf.bounce;
+        ps.rng = pt_rng_init(P.wf.hashes[s_idx], (uint64_t)pix);
+        ps.rng.n = sn & 0xfffu;
+        Hit h;
+        h.t = hh.x;
+        h.rec = __float_as_int(hh.y);
+        h.tri = -1;
+        v3 tri_n = V3(0.f, 0.f, 0.f);
+        tri_hit = h.t < PT_F32_MAX;
+        if (tri_hit) {   // a triangle was hit: its id (v0.w) and un-normalised normal (4th piece)
+            const float4 q3 = P.sc.nodes[h.rec + 3];
+            tri_n = V3(q3.x, q3.y, q3.z);
+            h.tri = 0;
+            if (P.tri_matid) h.tri = __float_as_int(P.sc.nodes[h.rec].w);
+        }
+        float* smp = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+        const SceneHit sh = pt_closest_sphere(P, ps.o, ps.d, h, 0);
+        if (sh.geom == 3) {   // tracer.cu:140-142: the sample IS the background colour, whatever was gathered before
+            PT_KARGS(K);
+            smp[0] = K.bk[0]; smp[1] = K.bk[1]; smp[2] = K.bk[2];
+        } else {
+            v3 col;
+            const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0);
+            const v3 e = done ? col : ps.accu;   // mask * emission of this hit (accu entered as 0)
+            if (!(e.x == 0.f) || !(e.y == 0.f) || !(e.z == 0.f)) {
+                smp[0] += e.x; smp[1] += e.y; smp[2] += e.z;
+            }
+            alive = !done;
+        }
+    }
+    if (COUNT) {   // all 64 lanes of every wave are here
+        const uint32_t nh = wave_sum_u32(tri_hit ? 1u : 0u), np = wave_sum_u32(have && !alive ? 1u : 0u);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&P.counters[4], (unsigned long long)nh);
+            atomicAdd(&P.counters[5], (unsigned long long)np);
+        }
+    }
+    if (last) return;   // every path ends with this bounce (tracer.cu:305)
+    int total;
+    const int r = wf_block_rank(alive, total, s_cnt);
+    if (alive) {
+        const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)r;
+        P.wf.ray0_out[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
+        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(pix), __uint_as_float((s_idx << 12) | ps.rng.n));
+        P.wf.mask_out[j] = ps.mask.x;
+        P.wf.mask_out[(size_t)P.wf.cap + j] = ps.mask.y;
+        P.wf.mask_out[2 * (size_t)P.wf.cap + j] = ps.mask.z;
+    }
+    if (threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = total;
+}
+
+namespace ptmi {
+
+int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) {
+    // limits of the record's packed fields: 12 bits of RNG draw count (<= 5 draws per bounce + 2), 20 bits of sample
+    if ((uint64_t)P.depth * 5u + 2u >= 4096u || P.spp >= (1u << 20))
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_KERNEL_WAVEFRONT packs <= 818 bounces and < 2^20 samples per call into a path record");
+    const size_t n_regions = ((size_t)work_tiles + PT_REGION / 64 - 1) / (PT_REGION / 64);
+    const size_t cap = n_regions * PT_REGION;
+    if (cap >= (1ull << 31)) return fail(c, PT_ERR_INVALID, "pt_render: too many path records for one call");
+    // carve: [ray0 x2][ray1 x2][mask x2 (3 planes)][hit][cnt x2][hashes][queues]
+    const size_t b_ray = cap * 16, b_mask = cap * 12, b_hit = cap * 8, b_cnt = ((n_regions * 4 + 255) / 256) * 256;
+    const size_t b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
+    const size_t q_words = (size_t)P.depth * PT_SHARDS * PT_SHARD_STRIDE, b_q = q_words * 4;
+    const size_t need = 4 * b_ray + 2 * b_mask + b_hit + 2 * b_cnt + b_hash + b_q;
+    if (need > c->wave_bytes) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_wave);
+        c->d_wave = nullptr;
+        c->wave_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->d_wave, need));
+        c->wave_bytes = need;
+    }
+    char* base = (char*)c->d_wave;
+    float4* ray0[2] = {(float4*)base, (float4*)(base + b_ray)};
+    float4* ray1[2] = {(float4*)(base + 2 * b_ray), (float4*)(base + 3 * b_ray)};
+    base += 4 * b_ray;
+    float* mask[2] = {(float*)base, (float*)(base + b_mask)};
+    base += 2 * b_mask;
+    float2* hit = (float2*)base;
+    base += b_hit;
+    int* cnt[2] = {(int*)base, (int*)(base + b_cnt)};
+    base += 2 * b_cnt;
+    unsigned long long* hashes = (unsigned long long*)base;
+    base += b_hash;
+    unsigned int* queues = (unsigned int*)base;
+
+    hipStream_t st = c->stream;
+    P.sc.n_top = 0;
+    P.sph_tab = 0;
+    P.batch = c->opt_wave_batch;
+    P.wf.hit = hit;
+    P.wf.hashes = hashes;
+    P.wf.queues_all = queues;
+    P.wf.queues_words = (uint32_t)q_words;
+    P.wf.cap = (uint32_t)cap;
+    P.wf.n_regions = (int)n_regions;
+    P.wf.bounce = 0;
+    hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(256), 0, st, P);
+    P.wf.ray0_out = ray0[0]; P.wf.ray1_out = ray1[0]; P.wf.mask_out = mask[0]; P.wf.cnt_out = cnt[0];
+    hipLaunchKernelGGL(k_wf_generate, dim3((unsigned)n_regions), dim3(PT_BLOCK), 0, st, P);
+    HIP_TRY(c, hipGetLastError());
+    if (stage_mark(c, PT_STAGE_GENERATE) != PT_OK) return PT_ERR_DEVICE;
+
+    const size_t lds_ext = (size_t)(L.lstk == 24 ? 24 : 16) * PT_BLOCK * 4;
+    const size_t lds_shade = 15 * PT_KSPHERES * 4;
+    for (uint32_t b = 0; b < P.depth; b++) {
+        const int g = (int)(b & 1u);
+        P.wf.bounce = b;
+        P.wf.ray0_in = ray0[g]; P.wf.ray1_in = ray1[g]; P.wf.mask_in = mask[g]; P.wf.cnt_in = cnt[g];
+        P.wf.ray0_out = ray0[g ^ 1]; P.wf.ray1_out = ray1[g ^ 1]; P.wf.mask_out = mask[g ^ 1]; P.wf.cnt_out = cnt[g ^ 1];
+        P.wf.queue = queues + (size_t)b * PT_SHARDS * PT_SHARD_STRIDE;
+#define PT_EXT(COUNT, OCC, LSTK)                                                                                  \
+        do {                                                                                                      \
+            int per_cu = 0;                                                                                       \
+            HIP_TRY(c, allow_lds(k_wf_extend<COUNT, OCC, LSTK>, lds_ext));                                        \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
+                per_cu = 1;                                                                                       \
+            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, n_regions)), \
+                               dim3(PT_BLOCK), lds_ext, st, P);                                                   \
+        } while (0)
+        if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24); else PT_EXT(true, 8, 16); }
+        else { if (L.lstk == 24) PT_EXT(false, 6, 24); else PT_EXT(false, 8, 16); }
+#undef PT_EXT
+        if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
+        if (L.count) hipLaunchKernelGGL(k_wf_shade<true>, dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P);
+        else hipLaunchKernelGGL(k_wf_shade<false>, dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P);
+        HIP_TRY(c, hipGetLastError());
+        if (stage_mark(c, PT_STAGE_SHADE) != PT_OK) return PT_ERR_DEVICE;
+    }
+    return PT_OK;
+}
+
+}  // namespace ptmi

@@ -109,6 +109,9 @@ inline bool parse(const float* nodes, size_t n_node_vec4, const float* tri_verts
                     for (int j = 0; j < 3; j++)
                         for (int x = 0; x < 3; x++) r.v[3 * j + x] = tri_verts[4 * (a + j) + x];
                     r.id = tri_index[a];
+                    // -1 is the walks' "miss" marker and ids index the per-triangle material rows; Woop
+                    // records carry id << 1 | last
+                    if (r.id < 0 || r.id >= (1 << 30)) { err = "triangle id out of range (0 .. 2^30-1)"; return false; }
                     T.refs.push_back(r);
                 }
                 lf.count = (uint32_t)T.refs.size() - lf.first;

@@ -53,6 +53,7 @@ struct TravStack {
     int lane_base;  // base + lane id.  Re-deriving the lane id at every access (v_mbcnt x2 + add) was the
                     // cheaper choice while ~120 SGPR spills ate the VGPR budget; with the kernel arguments
                     // read at use, one VGPR here saves ~12 VALU per node step (-1.4 % / -3.3 % at 8 / 6 waves)
+    uint32_t n_ovf = 0;  // pushes that went past the LDS window (read by the instrumented kernels only)
     __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK>& o) : base(b), ovf(o.e), lane_base(b + pt_lane_fresh()) {}
     __device__ __forceinline__ void put(int sp, int v) {
         if (LSTK >= PT_STACK_CAP || sp < LSTK) {
@@ -60,6 +61,7 @@ struct TravStack {
         } else {
             asm volatile("" : "+v"(v));
             ovf[sp - LSTK] = v;
+            n_ovf++;
         }
     }
     __device__ __forceinline__ int get(int sp) const {
@@ -276,16 +278,11 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
 // pt_woop_intersect in pt_math.h; tolerance-class parity (the triangle arithmetic differs).
 template <bool COUNT, bool DYN, bool TOP, bool WOOP, class STK>
 __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
-                                              TravCount& tc, int n_dead, int batch, int poll_index = -1, int poll_seen = 0) {
+                                              TravCount& tc, int n_dead, int batch) {
     int cur = s.node, sp = s.sp;
     Hit h = s.h;
     const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
-    int iter = 0;
     for (;;) {
-        // role-split kernel: lanes that found the ready queue empty watch its tail (an LDS word) every
-        // 8th step, so that new segments are picked up while the other lanes are still walking
-        if (DYN && poll_index >= 0 && n_dead > 0 && (++iter & 7) == 0 &&
-            __atomic_load_n(&((int*)s_dyn)[poll_index], __ATOMIC_RELAXED) != poll_seen) break;
         // phase vote: the wave runs ONE kind of step per iteration, the kind most live lanes are
         // waiting for; the others sit this iteration out.  Node and record lanes no longer both
         // pay for each other's code every iteration (the limiter is VALU issue).

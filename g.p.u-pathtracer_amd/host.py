@@ -251,6 +251,8 @@ def scene_mesh(name):
     cornell_dragon_800k : cornell ∪ 8 dragon copies under fixed transforms inside the box
                           (800 032 tris) — deterministic stand-in for the missing
                           Assets/cornell_dragon.obj blob (.MISSING_LARGE_BLOBS:3)
+    cornell_dragon_2700k / _6400k : cornell ∪ 27 / 64 dragon copies — item buffers of ~0.35 / ~0.8 GB,
+                          beyond the 256 MiB Infinity Cache (bench.py's extra workload)
     """
     if name == "cornell_box_dragon":
         # the material-carrying Cornell box (assets/cornell_box.ptmesh, lit by its own quad) with
@@ -285,6 +287,29 @@ def scene_mesh(name):
                     off = t - rot @ c
                     xf = np.concatenate([rot, off[:, None]], axis=1).astype(np.float32)
                     m.append(d, xf)
+                    k += 1
+        return m
+    if name in ("cornell_dragon_2700k", "cornell_dragon_6400k"):
+        # beyond the 256 MiB Infinity Cache (SURVEY.md §7 hard parts): cornell + an n x n x n lattice of dragon
+        # copies inside the box (n = 3: 2 700 032 triangles, n = 4: 6 400 032), each turned and scaled a little
+        n = 3 if name.endswith("2700k") else 4
+        m = Mesh.asset("cornell")
+        d = Mesh.asset("dragon")
+        lo, hi = d.bounds()
+        c = 0.5 * (lo + hi)
+        ext = float(np.max(hi - lo))
+        cell = np.array([26.0, 26.0, 27.0], np.float32) / n          # the box interior, cut into n^3 cells
+        k = 0
+        for iy in range(n):
+            for iz in range(n):
+                for ix in range(n):
+                    s = np.float32((0.8 + 0.05 * (k % 4)) * float(cell.min()) / ext)
+                    t = np.array([-13.0, -13.5, -57.0], np.float32) + cell * (np.array([ix, iy, iz], np.float32) + 0.5)
+                    ang = np.float32(0.35 * k)
+                    ca, sa = np.cos(ang), np.sin(ang)
+                    rot = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]], np.float32) * s
+                    off = t - rot @ c
+                    m.append(d, np.concatenate([rot, off[:, None]], axis=1).astype(np.float32))
                     k += 1
         return m
     return Mesh.asset(name)

@@ -152,10 +152,16 @@ class PathTracer:
         self._check(self._lib.pt_get_counters(self._ctx, C.byref(c)))
         return {f: getattr(c, f) for f, _ in Counters._fields_}
 
+    def stage_ms(self):
+        """Device ms of the last timed launch_kernel (PT_OPT_TIMING=1) by stage (pt_get_stage_ms)."""
+        out = (C.c_float * 6)()
+        self._check(self._lib.pt_get_stage_ms(self._ctx, out, 6))
+        return dict(zip(("none", "frame", "generate", "extend", "shade", "fold"), [float(v) for v in out]))
+
     def wave_stats(self):
-        out = (C.c_uint64 * 9)()
-        self._check(self._lib.pt_get_wave_stats(self._ctx, out, 9))
-        names = ("it_node", "act_node", "it_rec", "act_rec", "it_shade", "act_shade", "it_begin", "act_begin", "it_loop")
+        out = (C.c_uint64 * 10)()
+        self._check(self._lib.pt_get_wave_stats(self._ctx, out, 10))
+        names = ("it_node", "act_node", "it_rec", "act_rec", "it_shade", "act_shade", "it_begin", "act_begin", "it_loop", "stack_overflows")
         return dict(zip(names, [int(v) for v in out]))
 
     def last_kernel_ms(self):

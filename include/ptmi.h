@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 1
+#define PTMI_ABI_VERSION 2
 
 typedef struct pt_ctx pt_ctx;
 
@@ -82,9 +82,16 @@ enum {
     PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, one wave per 8x8 tile, bounce by bounce      */
     PT_KERNEL_MEGA_WIDE = 2, /* reserved: wide compressed nodes (not in this build)              */
     PT_KERNEL_PERSISTENT = 3,/* persistent waves: work queue, ballot/prefix-count lane refill    */
-    PT_KERNEL_WAVEFRONT = 4  /* stage split inside a block: tracer waves and shader waves exchange
-                                rays through LDS queues between segments (wide walk only; other
-                                settings fall back to PT_KERNEL_PERSISTENT)                      */
+    PT_KERNEL_ROLE_SPLIT = 4,/* removed in ABI 2 (round-1 experiment: tracer / shader waves inside a
+                                block; never ahead of PT_KERNEL_PERSISTENT); rejected
+                                with PT_ERR_UNSUPPORTED                                          */
+    PT_KERNEL_WAVEFRONT = 5  /* stage split (BASELINE.json configs[4]): path records in HBM, one
+                                launch per stage — generate, then per bounce extend (persistent
+                                waves walking the BVH, lanes refilled from the ray queue) and shade
+                                (one lane per live path; survivors compacted with a ballot /
+                                prefix count into the next generation).  Needs a BVH, depth >= 1
+                                and the wide walk over exact records; anything else runs
+                                PT_KERNEL_PERSISTENT.  Same images                                */
 };
 
 enum {
@@ -95,7 +102,7 @@ enum {
                                  leave the traversal loop to shade / refill; default 36      */
     PT_OPT_TOP_NODES = 5,     /* BVH nodes (breadth-first prefix, 0..1024) mirrored in LDS    */
     PT_OPT_OCCUPANCY = 6,     /* waves per SIMD the registers are budgeted for: 4/5/6/8 (default 6) */
-    PT_OPT_LDS_STACK = 7,     /* traversal-stack entries kept in LDS per lane: 16 (default) or
+    PT_OPT_LDS_STACK = 7,     /* traversal-stack entries kept in LDS per lane: 16 (default), 24 or
                                  0 = all 72; deeper entries overflow to private memory        */
     PT_OPT_WALK = 8,          /* closest-hit walk: 0 = while-while (Aila-Laine order, as the
                                  reference), 1 = unified-step over the binary tree,
@@ -109,8 +116,8 @@ enum {
                                  clamped to it (a wave must always have work to go to)          */
     PT_OPT_VOTE_NODE = 12,    /* walk 4: a wave runs a node step when                              */
     PT_OPT_VOTE_REC = 13,     /*   lanes_with_node * VOTE_NODE >= lanes_with_record * VOTE_REC (1, 1) */
-    PT_OPT_ROLES_BATCH = 14,  /* PT_KERNEL_WAVEFRONT: finished lanes (1..64) that make a tracer wave leave the
-                                 walk to hand its segments over and refill; default 16            */
+    PT_OPT_WAVE_BATCH = 14,   /* PT_KERNEL_WAVEFRONT, extend stage: finished lanes (1..64) that make a wave leave the
+                                 walk to store their hits and take new rays from the queue; default 16 */
     PT_OPT_SPHERE_LDS = 15,   /* persistent kernel: 1 (default) = the shading code reads the spheres from an LDS
                                  copy instead of scalar / global loads                            */
     PT_OPT_BUILD_ALGO = 16,   /* pt_build_bvh: 1 (default) = PLOC (locally-ordered clustering over Morton order:
@@ -275,10 +282,27 @@ int pt_get_counters(pt_ctx* ctx, pt_counters* out);
  * (PT_OPT_COUNTERS=1), summed over waves; up to PT_WAVE_STATS values:
  * [0] node-step iterations  [1] lanes active in them  [2] record-step iterations  [3] lanes
  * [4] shading passes        [5] lanes                 [6] path-start passes       [7] lanes
- * [8] outer-loop iterations.  A wave-iteration with all 64 lanes active is 100 % use. */
-#define PT_WAVE_STATS 9
+ * [8] outer-loop iterations  [9] traversal-stack pushes that overflowed the LDS window into
+ * private memory (PT_OPT_LDS_STACK).  A wave-iteration with all 64 lanes active is 100 % use.
+ * PT_KERNEL_WAVEFRONT: [0]-[3] and [6]-[9] are the extend stage's ([6]/[7] = refill passes), its
+ * shade stage runs one lane per live path ([4], [5] stay 0). */
+#define PT_WAVE_STATS 10
 int pt_get_wave_stats(pt_ctx* ctx, uint64_t* out, int n);
 int pt_last_kernel_ms(pt_ctx* ctx, float* ms_out);   /* needs PT_OPT_TIMING=1 */
+/* Device time of the last timed pt_render (PT_OPT_TIMING=1) by stage, from HIP events recorded on the
+ * context's stream between the launches: out[PT_STAGE_x] = milliseconds spent in that kind of launch,
+ * summed over the call (PT_KERNEL_WAVEFRONT runs `depth` extend and `depth` shade launches).  The
+ * reference's only timer is uf::GpuTimer around the whole launch (utilfun.hpp:44-79). */
+enum {
+    PT_STAGE_NONE = 0,      /* (start marker)                                                   */
+    PT_STAGE_FRAME = 1,     /* the frame kernel of PT_KERNEL_MEGA_BVH2 / PT_KERNEL_PERSISTENT      */
+    PT_STAGE_GENERATE = 2,  /* wavefront: prepare + camera rays                                   */
+    PT_STAGE_EXTEND = 3,    /* wavefront: closest-hit walks, all bounces                          */
+    PT_STAGE_SHADE = 4,     /* wavefront: spheres + shading + compaction, all bounces             */
+    PT_STAGE_FOLD = 5,      /* k_fold_samples: sample colours -> running mean + display word      */
+    PT_STAGE_COUNT = 6
+};
+int pt_get_stage_ms(pt_ctx* ctx, float* out, int n);
 int pt_scene_info(pt_ctx* ctx, uint64_t* n_inner, uint64_t* n_tri_refs,
                   uint64_t* n_leaves, uint32_t* max_depth, uint64_t* device_bytes);
 

@@ -1,0 +1,118 @@
+"""GPU parity at the configurations bench.py TIMES, with the library's DEFAULT kernel (no option set):
+the benchmarked path is the tested path.
+
+BASELINE.json configs[2] (cornell_dragon ~800k, 1920x1080, diffuse / metal / specular), the bench
+step itself (16 spp folded by ONE pt_render call: sample buffer + fold order of tracer.cu:386-391
+at full size) and configs[4] (dragon 4096x4096 at 8 spp).  Checker: the CPU oracle on the same
+seeded inputs.  Bar: north_star's per-pixel L2 < 1e-3 AND a stated cap on differing pixels (the wide
+walk's outward-rounded boxes may let a grazing candidate through that the binary tree culls; measured 0).
+"""
+import numpy as np
+import pytest
+
+import gpu_pathtracer_amd as g
+import orc
+from test_gpu_parity import gpu_render, l2, bvh_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["default", "wavefront", "persistent"])
+def ptd(request):
+    """default = whatever PT_KERNEL_AUTO picks (what bench.py times); the two stage layouts named too."""
+    t = g.PathTracer(0)
+    if request.param == "wavefront":
+        t.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
+    elif request.param == "persistent":
+        t.set_option(g.OPT_KERNEL, g.KERNEL_PERSISTENT)
+    t.variant = request.param
+    yield t
+    t.close()
+
+
+_oracle_cache = {}
+
+
+def oracle(key, fn):
+    """one oracle render per configuration, shared by the kernel variants"""
+    if key not in _oracle_cache:
+        _oracle_cache[key] = fn()
+    return _oracle_cache[key]
+
+
+def check(acc, ref, what, max_diff):
+    n_diff = int(np.any(acc != ref, axis=-1).sum())
+    err = l2(acc, ref)
+    print(f"{what}: L2 {err:.3e}, differing pixels {n_diff} of {acc.shape[0] * acc.shape[1]}")
+    assert err < 1e-3
+    assert n_diff <= max_diff
+
+
+def test_bench_step_16spp_800k_full_frame(ptd):
+    """THE bench step: cornell_dragon_800k, 1920x1080, depth 4, diffuse + sphere room, 16 spp in ONE call,
+    continuing a running mean (sample_index 17: the fold reads the accumulator of an earlier step)."""
+    W, H, spp = 1920, 1080, 16
+    _, bvh = bvh_of("cornell_dragon_800k")
+    sph = g.reference_spheres()
+    cam = g.default_camera(W, H)
+    p = g.default_params(W, H)
+    p.flags = g.FLAG_WRITE_RGBA
+    p.frame, p.sample_index = 16, 17
+    rng = np.random.default_rng(5)
+    prev = rng.random((H, W, 3), dtype=np.float32)
+    ref, ref_rgba, cnt = oracle("step16", lambda: orc.render(bvh, sph, cam, p, spp, accum=prev.copy()))
+    acc, rgba = gpu_render(ptd, bvh, sph, cam, p, spp, accum_init=prev)
+    assert cnt["rays"] == W * H * spp * p.depth          # the closed room: every path runs all four segments
+    check(acc, ref, f"[{ptd.variant}] 800k diffuse 16 spp/call", 40)
+    assert int((rgba != ref_rgba).sum()) <= 40
+
+
+@pytest.mark.parametrize("mat", [g.MAT_METAL, g.MAT_SPEC], ids=["metal", "specular"])
+def test_800k_metal_and_specular_full_frame(ptd, mat):
+    """configs[2]: the two other triangle materials bench.py times on the 800k scene."""
+    W, H, spp = 1920, 1080, 2
+    _, bvh = bvh_of("cornell_dragon_800k")
+    sph = g.reference_spheres()
+    cam = g.default_camera(W, H)
+    p = g.default_params(W, H, tri_mat=mat)
+    p.frame = 3
+    ref, _, _ = oracle(("mat", mat), lambda: orc.render(bvh, sph, cam, p, spp, want_rgba=False))
+    acc, _ = gpu_render(ptd, bvh, sph, cam, p, spp)
+    check(acc, ref, f"[{ptd.variant}] 800k mat {mat} {spp} spp", 40)
+
+
+def test_config5_dragon_4096_8spp(ptd):
+    """configs[4]: dragon.obj, 4096x4096, 8 spp in one call, open scene (paths end on their first miss:
+    the stage-split pipeline compacts them away between bounces, the persistent kernel refills lanes)."""
+    W = H = 4096
+    spp = 8
+    _, bvh = bvh_of("dragon")
+    cam = g.default_camera(W, H)
+    cam.dist = 18.0   # the reference's dist = H/60 = 68 would start every ray BEHIND the dragon
+    p = g.default_params(W, H)
+    ref, _, cnt = oracle("config5", lambda: orc.render(bvh, None, cam, p, spp, want_rgba=False))
+    acc, _ = gpu_render(ptd, bvh, None, cam, p, spp)
+    assert W * H * spp * 1.02 < cnt["rays"] < W * H * spp * p.depth
+    check(acc, ref, f"[{ptd.variant}] config5 dragon 4096^2 8 spp ({cnt['rays']} segments)", 256)
+
+
+def test_one_spp_calls_equal_one_multi_spp_call(ptd):
+    """render(accum, bvh, camera, spp) == spp launches of the reference (BasicScene.cpp:395-404), bit for bit,
+    at the bench resolution on the 100k scene."""
+    W, H, spp = 1920, 1080, 4
+    _, bvh = bvh_of("cornell_dragon")
+    sph = g.reference_spheres()
+    cam = g.default_camera(W, H)
+    p = g.default_params(W, H)
+    one, _ = gpu_render(ptd, bvh, sph, cam, p, spp)
+    ptd.upload_spheres(sph)
+    acc, rgba = ptd.alloc_frame(W, H)
+    for s in range(spp):
+        q = g.Params.from_buffer_copy(p)
+        q.frame, q.sample_index = p.frame + s, p.sample_index + s
+        ptd.launch_kernel(acc.ptr, rgba.ptr, cam, q, 1)
+    ptd.sync()
+    many = acc.download(np.float32, (H, W, 3))
+    acc.free()
+    rgba.free()
+    assert np.array_equal(one, many)

@@ -15,7 +15,7 @@ from test_gpu_parity import gpu_trace, golden_camera
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "mega-wide": (g.KERNEL_MEGA_BVH2, 2), "role-split": (g.KERNEL_WAVEFRONT, 2),
+VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "mega-wide": (g.KERNEL_MEGA_BVH2, 2), "wavefront": (g.KERNEL_WAVEFRONT, 2),
             "persistent-unified": (g.KERNEL_PERSISTENT, 1), "mega-whilewhile": (g.KERNEL_MEGA_BVH2, 0)}
 
 
@@ -188,7 +188,8 @@ def test_degenerate_inputs():
 
 
 def test_device_build_800k_speed_and_parity():
-    """The bench scene: build time, and the 1080p frame against the host-tree render of the same kernel."""
+    """The bench scene: build time, and the 1080p frame over the DEVICE-built tree against the ORACLE's
+    image over the host tree (the closest hit does not depend on the tree), plus the host-tree render."""
     mesh = g.scene_mesh("cornell_dragon_800k")
     W, H = 1920, 1080
     cam, p = g.default_camera(W, H), g.default_params(W, H)
@@ -204,15 +205,20 @@ def test_device_build_800k_speed_and_parity():
             acc.free()
             rgba.free()
             return a
-        t.upload_bvh(g.Bvh(mesh))
+        bvh = g.Bvh(mesh)
+        ref, _, _ = orc.render(bvh, sph, cam, p, 1, want_rgba=False)
+        t.upload_bvh(bvh)
         a_host = frame()
         ms = min(t.build_bvh(mesh) for _ in range(3))
         info = t.scene_info()
         a_dev = frame()
         n_diff = int(np.any(a_host != a_dev, axis=-1).sum())
-        print(f"800k: device build {ms:.1f} ms, {info}; differing pixels vs host tree {n_diff}")
+        n_orc = int(np.any(ref != a_dev, axis=-1).sum())
+        err = float(np.sqrt(np.mean(np.sum((a_dev.astype(np.float64) - ref) ** 2, axis=-1))))
+        print(f"800k: device build {ms:.1f} ms, {info}; differing pixels vs host tree {n_diff}, vs oracle {n_orc} (L2 {err:.2e})")
         assert ms < 200.0
         assert n_diff <= 40
+        assert err < 1e-3 and n_orc <= 40
     finally:
         t.close()
 

@@ -19,7 +19,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(scope="module", params=[(g.KERNEL_PERSISTENT, 2), (g.KERNEL_MEGA_BVH2, 2), (g.KERNEL_PERSISTENT, 4), (g.KERNEL_WAVEFRONT, 2)],
-                ids=["persistent-wide", "mega-wide", "persistent-wide-postponed-leaf", "role-split-wide"])
+                ids=["persistent-wide", "mega-wide", "persistent-wide-postponed-leaf", "wavefront-wide"])
 def ptw(request):
     t = g.PathTracer(0)
     t.set_option(g.OPT_KERNEL, request.param[0])

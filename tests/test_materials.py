@@ -109,7 +109,7 @@ def test_oracle_light_quad_lights_the_box():
 
 
 # ------------------------------------------------------------------------------ GPU parity
-GPU_VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "persistent-wide": (g.KERNEL_PERSISTENT, 2), "role-split": (g.KERNEL_WAVEFRONT, 2),
+GPU_VARIANTS = {"persistent-postponed": (g.KERNEL_PERSISTENT, 4), "persistent-wide": (g.KERNEL_PERSISTENT, 2), "wavefront": (g.KERNEL_WAVEFRONT, 2),
                 "mega-unified": (g.KERNEL_MEGA_BVH2, 1), "persistent-whilewhile": (g.KERNEL_PERSISTENT, 0)}
 
 

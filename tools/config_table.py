@@ -28,7 +28,7 @@ print(f"{'configuration':62s} {'kernel':>10s} {'ms/call':>9s} {'Msegments':>10s}
 for name, scene, W, H, spp, mat, spheres in CONFIGS:
     mesh = g.scene_mesh(scene)
     bvh = g.Bvh(mesh)
-    for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("role-split", g.KERNEL_WAVEFRONT)):
+    for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT)):
         pt = g.PathTracer(0)
         pt.set_option(g.OPT_KERNEL, kern)
         pt.upload_bvh(bvh)

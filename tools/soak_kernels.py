@@ -15,7 +15,7 @@ rng = np.random.default_rng(1)
 meshes = {n: g.scene_mesh(n) for n in ("cornell", "gto_sixteen", "cornell_dragon")}
 scenes = {n: g.Bvh(m) for n, m in meshes.items()}
 pts = {}
-for name, kern in (("persistent", g.KERNEL_PERSISTENT), ("role-split", g.KERNEL_WAVEFRONT), ("mega", g.KERNEL_MEGA_BVH2)):
+for name, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT), ("mega", g.KERNEL_MEGA_BVH2)):
     pts[name] = g.PathTracer(0)
     pts[name].set_option(g.OPT_KERNEL, kern)
 t0 = time.time()

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 __device__ __forceinline__ uint32_t mix(uint32_t x) {
@@ -84,7 +85,38 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ it
     out[gid] = acc;
 }
 
+// --json <n_items> <iters>: mode 0 only (one 64-byte item per lane per step, dependent chain, 8 waves/SIMD), on a
+// table of n_items and on a 2 MB table (every fetch an L2 hit: the ceiling of ANY per-lane walk); one JSON line
+// for bench.py, which runs this binary as a child process.
+static double run_mode0(uint32_t n_items, int iters) {
+    const int blocks = 256 * 8, threads = 256;
+    std::vector<float> h((size_t)n_items * 16);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) * 1e-3f;
+    float4* d_items; float* d_out;
+    if (hipMalloc(&d_items, h.size() * 4) != hipSuccess || hipMalloc(&d_out, (size_t)blocks * threads * 4) != hipSuccess) return 0.0;
+    hipMemcpy(d_items, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    hipFree(d_items); hipFree(d_out);
+    return (double)blocks * threads * iters / (best * 1e-3);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--json") {
+        const uint32_t n = argc > 2 ? (uint32_t)strtoul(argv[2], nullptr, 10) : 1000000u;
+        const int it = argc > 3 ? atoi(argv[3]) : 256;
+        const double a = run_mode0(n, it), b = run_mode0(32768u, it);
+        printf("{\"items_per_s\": %.6g, \"items_per_s_l2_resident\": %.6g, \"table_bytes\": %llu, \"iters\": %d}\n", a, b,
+               (unsigned long long)n * 64ull, it);
+        return a > 0 ? 0 : 1;
+    }
     const uint32_t n_items = argc > 1 ? (uint32_t)atoi(argv[1]) : 1000000u;  // 64 MB
     const int iters = argc > 2 ? atoi(argv[2]) : 256;
     const int blocks = 256 * 8, threads = 256;
