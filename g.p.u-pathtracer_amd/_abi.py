@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PTMI_PATH = os.path.join(_HERE, "csrc", "libptmi.so")
+# PT_LIBPTMI: another build of the same library (A/B experiments: tools/build_variant.sh); never a fallback
+PTMI_PATH = os.environ.get("PT_LIBPTMI") or os.path.join(_HERE, "csrc", "libptmi.so")
 PTHOST_PATH = os.path.join(_HERE, "host", "libpthost.so")
 
 
@@ -73,7 +74,7 @@ FLAG_METAL_LITERAL_W = 1 << 0
 FLAG_WRITE_RGBA = 1 << 1
 FLAG_FACE_FORWARD, FLAG_COSINE_DIFF, FLAG_GLASS_FIX, FLAG_RUSSIAN_ROULETTE = 1 << 2, 1 << 3, 1 << 4, 1 << 5
 KERNEL_AUTO, KERNEL_MEGA_BVH2, KERNEL_MEGA_WIDE, KERNEL_PERSISTENT, KERNEL_ROLE_SPLIT, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4, 5
-OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18
+OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT, OPT_WAVE_BLOCKS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19
 
 # every symbol include/ptmi.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32

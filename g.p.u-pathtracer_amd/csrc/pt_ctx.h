@@ -63,6 +63,7 @@ struct pt_ctx {
     void* d_wave = nullptr;
     size_t wave_bytes = 0;
     int opt_wave_batch = 16;     // extend kernel: finished lanes that make a wave leave the walk to write hits / refill
+    int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     // PT_OPT_TIMING: events between the stages of the last call (pt_get_stage_ms); stage_kind[i] is the

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             const int n_dead = queue_empty ? __popcll(__ballot(phase == PH_IDLE)) : 0;
             if (phase == PH_TRAV) {
                 const bool fin = (ALG == 4)   ? trav_run_wide_pend<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, P.vote_node, P.vote_rec)
-                                 : (ALG >= 2) ? trav_run_wide<COUNT, true, false, ALG == 3>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
+                                 : (ALG >= 2) ? trav_run_wide<COUNT, true, ALG == 3>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                  : (ALG == 1) ? trav_run_unified<COUNT, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch)
                                               : trav_run<COUNT, true, true>(ts, P.sc, ps.o, ps.d, cull, stk, tc, n_dead, P.batch, s_top);
                 if (fin) phase = PH_SHADE;

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
         // ---- walk until `batch` lanes have finished (lanes that can get no more work do not count)
         const int n_dead = empty ? 64 - __popcll(busy) : 0;
         if (live) {
-            const bool fin = trav_run_wide<COUNT, true, false, false>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
+            const bool fin = trav_run_wide<COUNT, true, false>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
             if (fin) {
                 P.wf.hit[idx] = make_float2(ts.h.t, __int_as_float(ts.h.rec));
                 live = false;
@@ -357,6 +357,7 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
             HIP_TRY(c, allow_lds(k_wf_extend<COUNT, OCC, LSTK>, lds_ext));                                        \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
                 per_cu = 1;                                                                                       \
+            per_cu = std::min(per_cu, c->opt_wave_blocks);                                                        \
             hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, n_regions)), \
                                dim3(PT_BLOCK), lds_ext, st, P);                                                   \
         } while (0)

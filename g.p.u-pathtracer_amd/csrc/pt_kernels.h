@@ -31,7 +31,7 @@ struct KScene {
     int n_top;     // nodes [top_base/4, top_base/4 + n_top) (breadth-first prefix) are mirrored in LDS
     int stack_n;   // LDS stack entries per lane
     int top_base;  // float4 index of the mirrored tree's root: 0 (binary) or wide_root
-    int wide_root; // float4 index of the 4-wide quantised tree's root (pt_wide.h), 0 if absent
+    int wide_root; // float4 index of the 4-wide quantised tree's root (= its node 0), 0 if absent
 };
 
 #define PT_KSPHERES 8   // spheres carried in the kernel-argument block (scalar loads); more -> global array
@@ -146,7 +146,7 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
             if (ALG >= 2) {
                 TravState ts;
                 trav_begin(ts, ps.o, ps.d, stk, P.sc.wide_root);
-                trav_run_wide<COUNT, false, false, ALG == 3, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
+                trav_run_wide<COUNT, false, ALG == 3, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
                 h = ts.h;
             } else if (ALG == 1) {
                 TravState ts;

@@ -268,15 +268,81 @@ __device__ __forceinline__ bool trav_run_unified(TravState& s, const KScene& sc,
 }
 
 // ---------------------------------------------------------------------------------------
-// Wide walk: unified-step over the 4-wide quantised tree of pt_wide.h.  A node item tests four
-// child boxes (24 v_cvt_f32_ubyte + 24 v_fma + min/max), sorts the hit children by entry
+// Wide walk: unified-step over the 4-wide quantised tree (pt_items.h).  A node item tests four
+// child boxes (24 v_cvt_f32_ubyte + 12 v_pk_fma + min/max), sorts the hit children by entry
 // distance with a 5-exchange network on (distance bits | child number) keys, continues with the
 // nearest and pushes the rest far-to-near.  Record items are the exact Moller-Trumbore test of
 // the other walks, so a reported hit is bit-identical to theirs; only the set of candidates the
-// (outward-rounded) boxes let through differs.  3 pieces for a record, 4 for a node.
+// (outward-rounded) boxes let through differs.
 // WOOP: records hold Woop's affine rows (PT_OPT_TRI_TEST 1) instead of v0/e1/e2 — see
-// pt_woop_intersect in pt_math.h; tolerance-class parity (the triangle arithmetic differs).
-template <bool COUNT, bool DYN, bool TOP, bool WOOP, class STK>
+//      pt_woop_intersect in pt_math.h; tolerance-class parity (the triangle arithmetic differs).
+// the three 16-byte pieces of an item as THREE global_load_dwordx4 issued back to back: every lane-level
+// vector-memory access costs the CU's address pipe the same whatever its width (tools/ubench_ta), and left alone
+// hipcc splits a piece whose .w is used apart from its .xyz into dwordx3 + dword (two accesses).  ONE asm pins all
+// twelve dwords after the three loads are in flight (a pin per piece would put a wait behind every load).
+__device__ __forceinline__ void pt_ld4x3(const float4* __restrict__ p, float4& q0, float4& q1, float4& q2) {
+    q0 = p[0]; q1 = p[1]; q2 = p[2];
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
+                      "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+}
+
+struct WideNode {
+    float ox, oy, oz, sx, sy, sz;            // origin, grid step per axis
+    uint32_t qlx, qly, qlz, qhx, qhy, qhz;   // lo / hi planes, child k in byte k
+    int l0, l1, l2, l3;                      // links: >= 0 float4 index of a node, < 0 ~(float4 index of a leaf's first record)
+};
+
+__device__ __forceinline__ WideNode wide_node_load(const KScene& sc, int a) {
+    WideNode w;
+    const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2], q3 = sc.nodes[a + 3];
+    w.ox = q0.x; w.oy = q0.y; w.oz = q0.z;
+    w.sx = q0.w; w.sy = q3.z; w.sz = q3.w;
+    w.qlx = __float_as_uint(q1.x); w.qly = __float_as_uint(q1.y); w.qlz = __float_as_uint(q1.z);
+    w.qhx = __float_as_uint(q1.w); w.qhy = __float_as_uint(q2.x); w.qhz = __float_as_uint(q2.y);
+    w.l0 = __float_as_int(q2.z); w.l1 = __float_as_int(q2.w);
+    w.l2 = __float_as_int(q3.x); w.l3 = __float_as_int(q3.y);
+    // keep the link words with the box words: left alone, hipcc sinks their use into the hit branches
+    // (two dependent round trips per node)
+    asm volatile("" : "+v"(w.l2), "+v"(w.l3));
+    return w;
+}
+
+// link of child (kk & 3)
+__device__ __forceinline__ int wide_link(const WideNode& w, uint32_t kk) {
+    const uint32_t k = kk & 3u;
+    return k == 0u ? w.l0 : (k == 1u ? w.l1 : (k == 2u ? w.l2 : w.l3));
+}
+
+// the four child-box tests of a node: keys = (entry distance bits | child number), 0xffffffff = missed; sorted ascending
+__device__ __forceinline__ void wide_node_keys(const WideNode& w, float idx, float idy, float idz, float oodx, float oody, float oodz,
+                                               float t_max, uint32_t key[4]) {
+    const float sx = w.sx * idx, sy = w.sy * idy, sz = w.sz * idz;  // per-axis grid step / direction
+    const float bx = fmaf(w.ox, idx, -oodx), by = fmaf(w.oy, idy, -oody), bz = fmaf(w.oz, idz, -oodz);
+    // entry/exit planes per axis follow the sign of the ray direction, so pick the packed
+    // byte quadruples ONCE per node (6 v_cndmask) instead of min/max per child (24):
+    // identical values to min(lo,hi)/max(lo,hi) of the reference's slab test
+    const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
+    const uint32_t nx = px ? w.qlx : w.qhx, fx = px ? w.qhx : w.qlx;
+    const uint32_t ny = py ? w.qly : w.qhy, fy = py ? w.qhy : w.qly;
+    const uint32_t nz = pz ? w.qlz : w.qhz, fz = pz ? w.qhz : w.qlz;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // (entry, exit) of one axis in one v_pk_fma_f32
+        const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
+        const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
+        const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
+        const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+        const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), t_max);
+        const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
+        key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
+    }
+    // sorting network for 4 keys: (0,1)(2,3)(0,2)(1,3)(1,2)
+#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+    PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+}
+
+template <bool COUNT, bool DYN, bool WOOP, class STK>
 __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
                                               TravCount& tc, int n_dead, int batch) {
     int cur = s.node, sp = s.sp;
@@ -285,7 +351,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
     for (;;) {
         // phase vote: the wave runs ONE kind of step per iteration, the kind most live lanes are
         // waiting for; the others sit this iteration out.  Node and record lanes no longer both
-        // pay for each other's code every iteration (the limiter is VALU issue).
+        // pay for each other's code every iteration.
         // The loop is wave-uniform: every lane that entered stays until the common exit.
         const bool live = cur != PT_SENTINEL;
         const bool is_node = live && cur >= 0;
@@ -301,95 +367,45 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         }
         if (!live || is_node != node_phase) continue;
         const int a = cur >= 0 ? cur : ~cur;
-        float4 q0, q1, q2;
-        float4 qw = make_float4(0.f, 0.f, 0.f, 0.f);  // WOOP: a record's 4th piece (normal | id<<1|last)
-        int l2 = 0, l3 = 0;
-        float sc_y = 0.f, sc_z = 0.f;
-        const int ti = a - sc.top_base;
-        if (TOP && cur >= 0 && (unsigned)ti < (unsigned)(sc.n_top * 4)) {
-            const int i = ti >> 2;
-            q0 = s_dyn[i];
-            q1 = s_dyn[sc.n_top + i];
-            q2 = s_dyn[2 * sc.n_top + i];
-            const float4 q3 = s_dyn[3 * sc.n_top + i];
-            l2 = __float_as_int(q3.x);
-            l3 = __float_as_int(q3.y);
-            sc_y = q3.z; sc_z = q3.w;
-            asm volatile("" : "+v"(q0.x), "+v"(l2));
-        } else {
-            q0 = sc.nodes[a + 0];
-            q1 = sc.nodes[a + 1];
-            q2 = sc.nodes[a + 2];
-            if (WOOP || cur >= 0) {
-                const float4 q3 = sc.nodes[a + 3];
-                l2 = __float_as_int(q3.x);
-                l3 = __float_as_int(q3.y);
-                sc_y = q3.z; sc_z = q3.w;
-                qw = q3;
-            }
-            asm volatile("" : "+v"(l2), "+v"(l3));
-        }
         if (cur >= 0) {
+            const WideNode w = wide_node_load(sc, a);
             if (COUNT) tc.inner++;
 #ifdef PT_EXP_LOAD   // sensitivity experiment: one more 16-byte access to the node's line per node step
-            { const float4 dummy = sc.nodes[a + 3]; asm volatile("" :: "v"(dummy.x), "v"(dummy.w)); }
+            { float4 dummy; const float4* ptr_ = sc.nodes + a + 2;   // a real second access to the same line (not CSE'd)
+              asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(dummy) : "v"(ptr_) : "memory");
+              asm volatile("" :: "v"(dummy.x), "v"(dummy.w)); }
 #endif
 #ifdef PT_EXP_VALU   // sensitivity experiment: 32 more dependent VALU instructions per node step
-            { float z = q0.x;
+            { float z = w.ox;
 #pragma unroll
               for (int e = 0; e < 32; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(z));
               asm volatile("" :: "v"(z)); }
 #endif
-            const float sx = q0.w * idx, sy = sc_y * idy, sz = sc_z * idz;  // per-axis grid step / direction
-            const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
-            // entry/exit planes per axis follow the sign of the ray direction, so pick the packed
-            // byte quadruples ONCE per node (6 v_cndmask) instead of min/max per child (24):
-            // identical values to min(lo,hi)/max(lo,hi) of the reference's slab test
-            const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
-            const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
-            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
-            const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx;
-            const uint32_t ny = py ? qly : qhy, fy = py ? qhy : qly;
-            const uint32_t nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
-            const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
             uint32_t key[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // (entry, exit) of one axis in one v_pk_fma_f32
-                const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
-                const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
-                const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
-                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
-                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
-                const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
-                key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
-            }
-            // sorting network for 4 keys: (0,1)(2,3)(0,2)(1,3)(1,2)
-#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
-            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
-#undef PT_CE
-#define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
-            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
-            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
+            wide_node_keys(w, idx, idy, idz, oodx, oody, oodz, h.t, key);
+            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, wide_link(w, key[3])); }
+            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, wide_link(w, key[2])); }
             if (key[1] != 0xffffffffu) {
-                const int lk = PT_LINK(key[1]);
+                const int lk = wide_link(w, key[1]);
                 sp++;
                 stk.put(sp, lk);
             }
             if (key[0] != 0xffffffffu) {
-                cur = PT_LINK(key[0]);
+                cur = wide_link(w, key[0]);
             } else {
                 cur = stk.get(sp);
                 sp--;
             }
-#undef PT_LINK
             if (COUNT && cur < 0) tc.leaves++;
         } else {
+            float4 q0, q1, q2;
+            pt_ld4x3(sc.nodes + a, q0, q1, q2);
             if (COUNT) tc.tris++;
             float t;
             int id;
             bool last;
             if (WOOP) {
+                const float4 qw = sc.nodes[a + 3];   // a record's 4th piece: normal | id << 1 | last
                 t = pt_woop_intersect(q0, q1, q2, V3(qw.x, qw.y, qw.z), o, d, cull);
                 id = __float_as_int(qw.w) >> 1;
                 last = (__float_as_int(qw.w) & 1) != 0;
@@ -411,7 +427,8 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
                 int aa = a;
                 while (!last) {
                     aa += 4;
-                    const float4 r0 = sc.nodes[aa], r1 = sc.nodes[aa + 1], r2 = sc.nodes[aa + 2];
+                    float4 r0, r1, r2;
+                    pt_ld4x3(sc.nodes + aa, r0, r1, r2);
                     if (COUNT) tc.tris++;
                     const float t2 = pt_mt_intersect(V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), V3(r2.x, r2.y, r2.z), o, d, cull);
                     const int id2 = __float_as_int(r0.w);
@@ -463,46 +480,19 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
         }
         if (node_phase) {
             if (!has_node) continue;
-            const int a = cur;
-            const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2], q3 = sc.nodes[a + 3];
-            int l2 = __float_as_int(q3.x), l3 = __float_as_int(q3.y);
-            const float sc_y = q3.z, sc_z = q3.w;
-            asm volatile("" : "+v"(l2), "+v"(l3));
+            const WideNode w = wide_node_load(sc, cur);
             if (COUNT) tc.inner++;
-            const float sx = q0.w * idx, sy = sc_y * idy, sz = sc_z * idz;  // per-axis grid step / direction
-            const float bx = fmaf(q0.x, idx, -oodx), by = fmaf(q0.y, idy, -oody), bz = fmaf(q0.z, idz, -oodz);
-            const uint32_t qlx = __float_as_uint(q1.x), qly = __float_as_uint(q1.y), qlz = __float_as_uint(q1.z);
-            const uint32_t qhx = __float_as_uint(q1.w), qhy = __float_as_uint(q2.x), qhz = __float_as_uint(q2.y);
-            const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
-            const uint32_t nx = px ? qlx : qhx, fx = px ? qhx : qlx;
-            const uint32_t ny = py ? qly : qhy, fy = py ? qhy : qly;
-            const uint32_t nz = pz ? qlz : qhz, fz = pz ? qhz : qlz;
-            const int l0 = __float_as_int(q2.z), l1 = __float_as_int(q2.w);
             uint32_t key[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
-                const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
-                const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
-                const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
-                const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), h.t);
-                const bool hit = tmin <= tmax;  // unused slots hold inverted boxes
-                key[k] = hit ? ((__float_as_uint(tmin) & 0x7ffffffcu) | (uint32_t)k) : 0xffffffffu;
-            }
-#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
-            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
-#undef PT_CE
-#define PT_LINK(kk) (((kk) & 3u) == 0u ? l0 : (((kk) & 3u) == 1u ? l1 : (((kk) & 3u) == 2u ? l2 : l3)))
-            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[3])); }
-            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[2])); }
-            if (key[1] != 0xffffffffu) { sp++; stk.put(sp, PT_LINK(key[1])); }
+            wide_node_keys(w, idx, idy, idz, oodx, oody, oodz, h.t, key);
+            if (key[3] != 0xffffffffu) { sp++; stk.put(sp, wide_link(w, key[3])); }
+            if (key[2] != 0xffffffffu) { sp++; stk.put(sp, wide_link(w, key[2])); }
+            if (key[1] != 0xffffffffu) { sp++; stk.put(sp, wide_link(w, key[1])); }
             if (key[0] != 0xffffffffu) {
-                cur = PT_LINK(key[0]);
+                cur = wide_link(w, key[0]);
             } else {
                 cur = stk.get(sp);
                 sp--;
             }
-#undef PT_LINK
             if (COUNT && cur < 0) tc.leaves++;
             if (cur < 0 && pend == 0) {  // park the leaf, go on with the next entry
                 pend = cur;
@@ -513,7 +503,8 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
         } else {
             if (!has_rec) continue;
             const int a = ~pend;
-            const float4 q0 = sc.nodes[a + 0], q1 = sc.nodes[a + 1], q2 = sc.nodes[a + 2];
+            float4 q0, q1, q2;
+            pt_ld4x3(sc.nodes + a, q0, q1, q2);
             if (COUNT) tc.tris++;
             const v3 v0 = V3(q0.x, q0.y, q0.z), e1 = V3(q1.x, q1.y, q1.z), e2 = V3(q2.x, q2.y, q2.z);
             const float t = pt_mt_intersect(v0, e1, e2, o, d, cull);

@@ -151,6 +151,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: vote weight must be 1..64");
             (option == PT_OPT_VOTE_NODE ? c->opt_vote_node : c->opt_vote_rec) = value;
             return PT_OK;
+        case PT_OPT_WAVE_BLOCKS:
+            if (value < 1 || value > 8) return fail(c, PT_ERR_INVALID, "pt_set_option: wave blocks must be 1..8 per CU");
+            c->opt_wave_blocks = value;
+            return PT_OK;
         case PT_OPT_LDS_STACK:
             if (value != 0 && value != 16 && value != 24) return fail(c, PT_ERR_INVALID, "pt_set_option: LDS stack must be 0 (all 72 entries in LDS), 16 or 24 entries");
             c->opt_lstk = value;

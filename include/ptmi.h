@@ -120,6 +120,9 @@ enum {
                                  walk to store their hits and take new rays from the queue; default 16 */
     PT_OPT_SPHERE_LDS = 15,   /* persistent kernel: 1 (default) = the shading code reads the spheres from an LDS
                                  copy instead of scalar / global loads                            */
+    PT_OPT_WAVE_BLOCKS = 19,  /* PT_KERNEL_WAVEFRONT, extend stage: resident 256-thread blocks per CU its persistent grid is
+                                 sized for, 1..8 (default 8 = 8 waves per SIMD); fewer leave room for another
+                                 context's launches on the same device                                 */
     PT_OPT_BUILD_ALGO = 16,   /* pt_build_bvh: 1 (default) = PLOC (locally-ordered clustering over Morton order:
                                  a tree as good as the host SAH/SBVH builder's, ~6.5 ms for 800 k triangles;
                                  degenerate input falls back to 0), 0 = LBVH (Karras hierarchy: 1.8 ms, a

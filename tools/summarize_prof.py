@@ -42,7 +42,7 @@ def main(out):
             for r in csv.DictReader(open(f)):
                 acc[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
             for k, cs in acc.items():
-                if "trace" not in k:
+                if "trace" not in k and "k_wf" not in k and "k_fold" not in k:
                     continue
                 for c, vals in cs.items():
                     m = sum(vals) / len(vals)
