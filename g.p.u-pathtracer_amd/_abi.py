@@ -72,7 +72,10 @@ class BvhStats(C.Structure):
 MAT_DIFF, MAT_METAL, MAT_SPEC, MAT_REFR = 0, 1, 2, 3
 FLAG_METAL_LITERAL_W = 1 << 0
 FLAG_WRITE_RGBA = 1 << 1
-FLAG_FACE_FORWARD, FLAG_COSINE_DIFF, FLAG_GLASS_FIX, FLAG_RUSSIAN_ROULETTE = 1 << 2, 1 << 3, 1 << 4, 1 << 5
+FLAG_FACE_FORWARD, FLAG_COSINE_DIFF, FLAG_GLASS_FIX, FLAG_RUSSIAN_ROULETTE, FLAG_MISS_KEEPS_PATH = 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6
+FLAG_RR_CPU_TRACER = 1 << 7
+FLAGS_SMALLPT = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RUSSIAN_ROULETTE | FLAG_MISS_KEEPS_PATH
+FLAGS_CPU_TRACER = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RR_CPU_TRACER | FLAG_MISS_KEEPS_PATH
 KERNEL_AUTO, KERNEL_MEGA_BVH2, KERNEL_MEGA_WIDE, KERNEL_PERSISTENT, KERNEL_ROLE_SPLIT, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4, 5
 OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT, OPT_WAVE_BLOCKS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19
 
@@ -103,6 +106,7 @@ PTMI_SYMBOLS = [
     ("pt_get_wave_stats", _i, [_vp, C.POINTER(C.c_uint64), _i]),
     ("pt_last_kernel_ms", _i, [_vp, C.POINTER(C.c_float)]),
     ("pt_get_stage_ms", _i, [_vp, C.POINTER(C.c_float), _i]),
+    ("pt_auto_choice", _i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("pt_scene_info", _i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
 ]

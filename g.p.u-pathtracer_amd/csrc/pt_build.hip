@@ -244,6 +244,7 @@ int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t*
     c->max_tri_id = (int32_t)n_tris - 1;
     if (id_map) for (size_t i = 0; i < n_tris; i++) c->max_tri_id = std::max(c->max_tri_id, id_map[i]);
     c->has_bvh = true;
+    c->scene_gen++;
     return PT_OK;
 }
 

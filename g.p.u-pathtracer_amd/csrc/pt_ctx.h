@@ -64,6 +64,17 @@ struct pt_ctx {
     size_t wave_bytes = 0;
     int opt_wave_batch = 16;     // extend kernel: finished lanes that make a wave leave the walk to write hits / refill
     int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
+    // PT_KERNEL_AUTO: which stage layout is faster depends on the workload (long paths and many samples per call:
+    // the stage-split pipeline; short paths or few samples: the persistent kernel), so the first two calls of a
+    // configuration time one each (HIP events on the stream) and the following ones run the faster
+    struct AutoPick {
+        uint64_t key = 0;        // what the choice was made for: image, spp, depth, partition, scene generation
+        int phase = 0;           // 0: time the persistent kernel  1: time the pipeline  2: read the events  3: decided
+        int choice = PT_KERNEL_PERSISTENT;
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        float ms[2] = {0.f, 0.f};
+    } pick;
+    uint64_t scene_gen = 0;      // bumped by every upload / build
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     // PT_OPT_TIMING: events between the stages of the last call (pt_get_stage_ms); stage_kind[i] is the

@@ -258,7 +258,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
         const SceneHit sh = pt_closest_sphere(P, ps.o, ps.d, h, 0);
         if (sh.geom == 3) {   // tracer.cu:140-142: the sample IS the background colour, whatever was gathered before
             PT_KARGS(K);
-            smp[0] = K.bk[0]; smp[1] = K.bk[1]; smp[2] = K.bk[2];
+            if (K.flags & PT_FLAG_MISS_KEEPS_PATH) {   // extension: accu (= the sample buffer) + mask * bk
+                smp[0] += ps.mask.x * K.bk[0]; smp[1] += ps.mask.y * K.bk[1]; smp[2] += ps.mask.z * K.bk[2];
+            } else {
+                smp[0] = K.bk[0]; smp[1] = K.bk[1]; smp[2] = K.bk[2];
+            }
         } else {
             v3 col;
             const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0);

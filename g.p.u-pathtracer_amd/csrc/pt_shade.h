@@ -148,6 +148,7 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
         }
     } else {
         col_out = V3(K.bk[0], K.bk[1], K.bk[2]);  // tracer.cu:140-142: unmasked background
+        if (K.flags & PT_FLAG_MISS_KEEPS_PATH) col_out = vadd(accu, vmul(mask, col_out));  // extension
         return true;
     }
     accu = vadd(accu, vmul(mask, emit));
@@ -156,6 +157,12 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
         const float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
         if (!(pt_rng_next(rng) < pr)) { col_out = accu; return true; }
         objcol = vscale(objcol, 1.0f / pr);
+    }
+
+    if ((K.flags & PT_FLAG_RR_CPU_TRACER) && ps.depth >= 5) {  // extension: CpuRayTracer/src/scene.cpp:38-47
+        const float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
+        if (!(pt_rng_next(rng) < pr * 0.9f)) { col_out = accu; return true; }
+        objcol = vscale(objcol, 0.9f / pr);
     }
 
     v3 nextdir;

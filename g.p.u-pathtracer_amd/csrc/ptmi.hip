@@ -89,6 +89,7 @@ int pt_destroy(pt_ctx* c) {
     (void)hipFree(c->d_samples);
     (void)hipFree(c->d_wave);
     for (hipEvent_t e : c->stage_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->pick.e) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -296,6 +297,7 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     c->scene_bytes = nb + tb + wb;
     c->max_tri_id = max_id;
     c->has_bvh = true;
+    c->scene_gen++;
     return PT_OK;
 }
 
@@ -444,7 +446,41 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     // records; every other request for it runs the persistent kernel (same images)
     const bool wave_ok = c->has_bvh && P.depth > 0 && walk == 2;
     int kernel = c->opt_kernel;
-    if (kernel == PT_KERNEL_AUTO) kernel = PT_KERNEL_PERSISTENT;
+    int probe = -1;   // PT_KERNEL_AUTO: 0 / 1 = this call is the timed trial of the persistent kernel / the pipeline
+    if (kernel == PT_KERNEL_AUTO) {
+        kernel = PT_KERNEL_PERSISTENT;
+        if (wave_ok && !c->opt_counters) {
+            pt_ctx::AutoPick& a = c->pick;
+            uint64_t key = 0xcbf29ce484222325ull;
+            const uint64_t parts[] = {(uint64_t)p->width, (uint64_t)p->height, (uint64_t)spp, (uint64_t)p->depth, (uint64_t)p->part_index,
+                                      (uint64_t)p->part_count, (uint64_t)p->part_rows, c->scene_gen, (uint64_t)c->n_spheres,
+                                      (uint64_t)p->tri_mat, (uint64_t)(p->flags & ~(uint32_t)PT_FLAG_WRITE_RGBA)};
+            for (uint64_t v : parts) { key ^= v; key *= 0x100000001b3ull; }
+            if (key != a.key) { a.key = key; a.phase = 0; }
+            if (a.phase == 2) {   // both trials are queued or done: read their times (waits for them if need be)
+                bool ok = true;
+                for (int t = 0; t < 2 && ok; t++)
+                    ok = hipEventSynchronize(a.e[2 * t + 1]) == hipSuccess && hipEventElapsedTime(&a.ms[t], a.e[2 * t], a.e[2 * t + 1]) == hipSuccess;
+                a.choice = ok && a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;
+                a.phase = 3;
+                if (a.choice == PT_KERNEL_PERSISTENT && c->d_wave) {   // the pipeline's path records are not needed
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    (void)hipFree(c->d_wave);
+                    c->d_wave = nullptr;
+                    c->wave_bytes = 0;
+                }
+            }
+            if (a.phase < 2) {
+                for (hipEvent_t& e : a.e)
+                    if (!e) HIP_TRY(c, hipEventCreate(&e));
+                probe = a.phase;
+                kernel = probe == 0 ? PT_KERNEL_PERSISTENT : PT_KERNEL_WAVEFRONT;
+                a.phase++;
+            } else {
+                kernel = a.choice;
+            }
+        }
+    }
     if (kernel == PT_KERNEL_WAVEFRONT && !wave_ok) kernel = PT_KERNEL_PERSISTENT;
     if (kernel == PT_KERNEL_MEGA_BVH2 && walk == 3) kernel = PT_KERNEL_PERSISTENT;   // Woop records: persistent kernel only
     const bool persistent = kernel == PT_KERNEL_PERSISTENT;
@@ -468,6 +504,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     const int work_tiles = P.n_tiles * (P.samples ? (int)spp : 1);
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe], c->stream));
     if (c->opt_timing) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         c->stage_used = 0;
@@ -528,7 +565,16 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         HIP_TRY(c, launch_fold(P, c->stream));
         if (stage_mark(c, PT_STAGE_FOLD) != PT_OK) return PT_ERR_DEVICE;
     }
+    if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe + 1], c->stream));
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
+    return PT_OK;
+}
+
+int pt_auto_choice(pt_ctx* c, int* kernel, float* ms_persistent, float* ms_wavefront) {
+    if (!c || !kernel) return fail(c, PT_ERR_INVALID, "pt_auto_choice: null argument");
+    *kernel = c->pick.phase >= 3 ? c->pick.choice : PT_KERNEL_AUTO;
+    if (ms_persistent) *ms_persistent = c->pick.ms[0];
+    if (ms_wavefront) *ms_wavefront = c->pick.ms[1];
     return PT_OK;
 }
 

@@ -158,6 +158,12 @@ class PathTracer:
         self._check(self._lib.pt_get_stage_ms(self._ctx, out, 6))
         return dict(zip(("none", "frame", "generate", "extend", "shade", "fold"), [float(v) for v in out]))
 
+    def auto_choice(self):
+        """PT_KERNEL_AUTO's pick for the last configuration: (kernel or KERNEL_AUTO while undecided, ms persistent, ms wavefront)."""
+        k, a, b = C.c_int(), C.c_float(), C.c_float()
+        self._check(self._lib.pt_auto_choice(self._ctx, C.byref(k), C.byref(a), C.byref(b)))
+        return k.value, a.value, b.value
+
     def wave_stats(self):
         out = (C.c_uint64 * 10)()
         self._check(self._lib.pt_get_wave_stats(self._ctx, out, 10))

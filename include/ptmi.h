@@ -72,13 +72,34 @@ enum {
                                         where it should divide), reflection chosen with probability
                                         P = .25 + .5 Re (the weights RP/TP assume it; the reference
                                         uses 0.2), transmitted rays start on the far side (-nl)       */
-    PT_FLAG_RUSSIAN_ROULETTE = 1u << 5 /* from the 3rd segment on: continue with probability
+    PT_FLAG_RUSSIAN_ROULETTE = 1u << 5,/* from the 3rd segment on: continue with probability
                                         p = max(col) and divide col by p, else end the path          */
+    PT_FLAG_RR_CPU_TRACER = 1u << 7,   /* Russian roulette exactly as the reference's CPU tracer plays it
+                                        (CpuRayTracer/src/scene.cpp:38-47): from the 6th hit of a path on, continue
+                                        with probability 0.9 p, p = max(col), and scale col by 0.9 / p — an expected
+                                        0.81 per bounce: that renderer's energy loss, reproduced so that its images
+                                        can be matched; PT_FLAG_RUSSIAN_ROULETTE is the unbiased one            */
+    PT_FLAG_MISS_KEEPS_PATH = 1u << 6  /* a segment that hits nothing ends the path with
+                                        accu + mask * bk_color (smallpt, and the reference's own CPU
+                                        tracer: CpuRayTracer/src/scene.cpp:27 returns black for the
+                                        MISSING TERM only) instead of the reference GPU kernel's bare
+                                        bk_color, which throws the gathered light away
+                                        (tracer.cu:140-142)                                          */
 };
+/* The estimator of the reference's CPU tracer (CpuRayTracer/src/scene.cpp:23-56, material.cpp:24-45: smallpt's):
+ * cosine-weighted diffuse lobe, normals facing the ray, Russian roulette, light only where a path ENDS on
+ * emission.  With bk_color = 0, an emitter given col = 0 and a generous depth the expected radiance equals
+ * that renderer's (tests/test_reference_radiance.py compares them). */
+#define PT_FLAGS_SMALLPT (PT_FLAG_FACE_FORWARD | PT_FLAG_COSINE_DIFF | PT_FLAG_RUSSIAN_ROULETTE | PT_FLAG_MISS_KEEPS_PATH)
+/* ... and with that renderer's own roulette instead of the unbiased one: its images, bias included */
+#define PT_FLAGS_CPU_TRACER (PT_FLAG_FACE_FORWARD | PT_FLAG_COSINE_DIFF | PT_FLAG_RR_CPU_TRACER | PT_FLAG_MISS_KEEPS_PATH)
 
 /* pt_ctx kernel selection (pt_set_option PT_OPT_KERNEL) */
 enum {
-    PT_KERNEL_AUTO = 0,      /* fastest validated variant (currently PT_KERNEL_PERSISTENT)       */
+    PT_KERNEL_AUTO = 0,      /* PT_KERNEL_PERSISTENT or PT_KERNEL_WAVEFRONT, whichever is faster for the
+                                configuration (image, samples per call, depth, partition, scene): its first
+                                two pt_render calls time one each with HIP events and the following ones
+                                run the faster (the images are the same); pt_auto_choice reports it    */
     PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, one wave per 8x8 tile, bounce by bounce      */
     PT_KERNEL_MEGA_WIDE = 2, /* reserved: wide compressed nodes (not in this build)              */
     PT_KERNEL_PERSISTENT = 3,/* persistent waves: work queue, ballot/prefix-count lane refill    */
@@ -306,6 +327,9 @@ enum {
     PT_STAGE_COUNT = 6
 };
 int pt_get_stage_ms(pt_ctx* ctx, float* out, int n);
+/* PT_KERNEL_AUTO's pick for the configuration of the last pt_render: *kernel = PT_KERNEL_PERSISTENT or
+ * PT_KERNEL_WAVEFRONT once decided (PT_KERNEL_AUTO while the two trials are still running), and the two trial times. */
+int pt_auto_choice(pt_ctx* ctx, int* kernel, float* ms_persistent, float* ms_wavefront);
 int pt_scene_info(pt_ctx* ctx, uint64_t* n_inner, uint64_t* n_tri_refs,
                   uint64_t* n_leaves, uint32_t* max_depth, uint64_t* device_bytes);
 

@@ -435,7 +435,9 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
                 phong = m->phong_expo;
             }
         } else {
-            return V(P->bk_color[0], P->bk_color[1], P->bk_color[2]); /* tracer.cu:140-142 */
+            const v3 bk = V(P->bk_color[0], P->bk_color[1], P->bk_color[2]);
+            if (P->flags & PT_FLAG_MISS_KEEPS_PATH) return vadd(accu, vmul(mask, bk)); /* extension (ptmi.h) */
+            return bk; /* tracer.cu:140-142 */
         }
         accu = vadd(accu, vmul(mask, emit));
 
@@ -443,6 +445,12 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
             if (!(rng_next(rng) < pr)) return accu;
             objcol = vscale(objcol, 1.0f / pr);
+        }
+
+        if ((P->flags & PT_FLAG_RR_CPU_TRACER) && depth >= 5) { /* extension: CpuRayTracer/src/scene.cpp:38-47 */
+            float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
+            if (!(rng_next(rng) < pr * 0.9f)) return accu;
+            objcol = vscale(objcol, 0.9f / pr);
         }
 
         v3 nextdir;

@@ -123,7 +123,49 @@ def make_cornell_compact():
     print("cornell compact:", b.nodes.shape, b.tris.shape, b.index.shape)
 
 
+# ---- radiance of the REFERENCE's CPU tracer on its own room (CpuRayTracer/src/main.cpp:26-35) ------------------
+REF_W, REF_H, REF_SPP, REF_BLOCK = 160, 120, 400, 20
+REF_MESH_POS = (0.3, 0.2, 0.0)
+
+
+def ref_room_mesh():
+    """bunny_low turned z-up, 2.4 units tall, standing on the z = 0 floor of main.cpp's room."""
+    mesh = g.scene_mesh("bunny_low")
+    v, f = mesh.verts.astype(np.float64), mesh.tris
+    lo, hi = v.min(0), v.max(0)
+    c, ext = 0.5 * (lo + hi), float(np.max(hi - lo))
+    v = (v - c) * (2.4 / ext)
+    v = np.stack([v[:, 0], -v[:, 2], v[:, 1]], -1)
+    v[:, 2] -= v[:, 2].min()
+    return v.astype(np.float32), f
+
+
+def make_ref_render():
+    """oracle/_ref render = Scene::trace_ray / Material::get_reflected_ray / Sphere / Mesh / KDNode of the reference,
+    compiled from /root/reference, on main.cpp's room + a mesh.  Kept as block means (a 160x120 image at 400 spp is
+    still noisy per pixel; 20x20 blocks average 160 000 paths each)."""
+    if not os.path.exists(orc.REF_BIN):
+        print("skip ref_room_radiance (needs oracle/_ref)")
+        return
+    v, f = ref_room_mesh()
+    with tempfile.TemporaryDirectory() as td:
+        obj, out = os.path.join(td, "m.obj"), os.path.join(td, "img.f32")
+        with open(obj, "w") as fh:
+            fh.write("o mesh\n")
+            np.savetxt(fh, v, fmt="v %.7f %.7f %.7f")
+            np.savetxt(fh, f + 1, fmt="f %d %d %d")
+        r = subprocess.run([orc.REF_BIN, "render", obj, str(REF_W), str(REF_H), str(REF_SPP)] + [str(x) for x in REF_MESH_POS] + [out],
+                           capture_output=True, text=True, check=True)
+        img = np.fromfile(out, np.float32).reshape(REF_H, REF_W, 3)
+    blocks = img.reshape(REF_H // REF_BLOCK, REF_BLOCK, REF_W // REF_BLOCK, REF_BLOCK, 3).mean(axis=(1, 3))
+    np.savez_compressed(os.path.join(HERE, "ref_room_radiance.npz"), blocks=blocks.astype(np.float32), mean=np.float32(img.mean()),
+                        verts=v, tris=f.astype(np.int32), width=REF_W, height=REF_H, spp=REF_SPP, block=REF_BLOCK,
+                        mesh_pos=np.array(REF_MESH_POS, np.float32))
+    print("reference room radiance:", r.stdout.strip().splitlines()[-1], "block means", blocks.mean(axis=-1).round(3).tolist())
+
+
 if __name__ == "__main__":
+    make_ref_render()
     make_ref_hits()
     make_oracle_images()
     make_kat()

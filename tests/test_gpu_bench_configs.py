@@ -116,3 +116,37 @@ def test_one_spp_calls_equal_one_multi_spp_call(ptd):
     acc.free()
     rgba.free()
     assert np.array_equal(one, many)
+
+
+def test_auto_times_both_layouts_and_keeps_one():
+    """PT_KERNEL_AUTO: the first two calls of a configuration are the timed trials (persistent kernel, stage-split
+    pipeline), the third runs the faster; every call gives the same image."""
+    W, H, spp = 1280, 720, 8
+    _, bvh = bvh_of("cornell_dragon")
+    sph = g.reference_spheres()
+    cam = g.default_camera(W, H)
+    p = g.default_params(W, H)
+    t = g.PathTracer(0)
+    try:
+        t.upload_bvh(bvh)
+        t.upload_spheres(sph)
+        acc, rgba = t.alloc_frame(W, H)
+        frames = []
+        for i in range(4):
+            acc.zero()
+            t.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+            t.sync()
+            frames.append(acc.download(np.float32, (H, W, 3)))
+            k, ms_p, ms_w = t.auto_choice()
+            if i < 2:
+                assert k == g.KERNEL_AUTO          # still measuring
+        assert k in (g.KERNEL_PERSISTENT, g.KERNEL_WAVEFRONT) and ms_p > 0 and ms_w > 0
+        print(f"auto: persistent {ms_p:.3f} ms, wavefront {ms_w:.3f} ms -> {'wavefront' if k == g.KERNEL_WAVEFRONT else 'persistent'}")
+        for f in frames[1:]:
+            assert np.array_equal(f, frames[0])
+        # another configuration starts over
+        t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 1)
+        t.sync()
+        assert t.auto_choice()[0] == g.KERNEL_AUTO
+    finally:
+        t.close()

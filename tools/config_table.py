@@ -23,6 +23,8 @@ CONFIGS = [
     ("C3 cornell_dragon 800k 1920x1080 diffuse, 1 spp per call", "cornell_dragon_800k", 1920, 1080, 1, g.MAT_DIFF, True),
     ("C4 gto_sixteen 1920x1080", "gto_sixteen", 1920, 1080, 16, g.MAT_DIFF, True),
     ("C5 dragon 4096x4096 8 spp (open)", "dragon", 4096, 4096, 8, g.MAT_DIFF, False),
+    ("C5 dragon 4096x4096 1 spp (open)", "dragon", 4096, 4096, 1, g.MAT_DIFF, False),
+    ("C3 cornell_dragon 800k 1920x1080 diffuse, 4 spp per call", "cornell_dragon_800k", 1920, 1080, 4, g.MAT_DIFF, True),
 ]
 print(f"{'configuration':62s} {'kernel':>10s} {'ms/call':>9s} {'Msegments':>10s} {'Mrays/s':>9s}")
 for name, scene, W, H, spp, mat, spheres in CONFIGS:
@@ -34,6 +36,8 @@ for name, scene, W, H, spp, mat, spheres in CONFIGS:
         pt.upload_bvh(bvh)
         pt.upload_spheres(g.reference_spheres() if spheres else None)
         cam = g.default_camera(W, H)
+        if scene == "dragon":
+            cam.dist = 18.0   # the reference dist = H/60 would start every ray behind the dragon
         acc, rgba = pt.alloc_frame(W, H)
         def launch(f):
             p = g.default_params(W, H, tri_mat=mat)
