@@ -64,11 +64,15 @@ def parse():
     ap.add_argument("--lds-stack", type=int, default=-1, help="PT_OPT_LDS_STACK (-1 = library default)")
     ap.add_argument("--top", type=int, default=-1, help="PT_OPT_TOP_NODES (-1 = library default)")
     ap.add_argument("--batch", type=int, default=0, help="PT_OPT_BATCH / PT_OPT_WAVE_BATCH (0 = library default)")
+    ap.add_argument("--no-overlap", action="store_true", help="PT_OPT_OVERLAP 0: every launch on the caller's stream")
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=1, help="steps of the workload run on the CPU oracle: baseline + parity (0 = skip)")
     ap.add_argument("--no-cpu-reference", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (materials, 1 spp, device tree, big scene, gather bound)")
     ap.add_argument("--device-build", action="store_true", help="build the BVH on the device (pt_build_bvh) instead of the host SBVH builder")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still initialise torch.distributed over RCCL (backend nccl, world 1) and send every step's "
+                         "display words through the same all_gather_into_tensor / side-stream path the N > 1 runs use")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dry run on a ONE-GPU box: every rank uses cuda:0, gloo backend, stripes gathered "
                          "through host memory (validates the multi-rank code path, not its speed)")
@@ -182,8 +186,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # --force-dist: a one-rank RCCL group, no torchrun needed
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+            s_.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.rehearse:
             dist.init_process_group("gloo")
         else:
@@ -214,6 +226,8 @@ def main():
         pt.set_option(g.OPT_LDS_STACK, a.lds_stack)
     if a.top >= 0:
         pt.set_option(g.OPT_TOP_NODES, a.top)
+    if a.no_overlap:
+        pt.set_option(g.OPT_OVERLAP, 0)
     if a.batch:
         pt.set_option(g.OPT_BATCH, a.batch)
         pt.set_option(g.OPT_WAVE_BATCH, a.batch)
@@ -232,7 +246,7 @@ def main():
     accum = torch.zeros((layout.padded_height, W, 3), dtype=torch.float32, device=dev)
     # display words are double-buffered so that the gather of frame i (side stream, RCCL)
     # overlaps the render of frame i+1 (main stream); PT_BENCH_NO_OVERLAP=1 serialises them
-    overlap = world > 1 and not a.rehearse and os.environ.get("PT_BENCH_NO_OVERLAP", "0") != "1"
+    overlap = use_dist and not a.rehearse and os.environ.get("PT_BENCH_NO_OVERLAP", "0") != "1"
     n_buf = 2 if overlap else 1
     rgbas = [torch.zeros((layout.padded_height, W), dtype=torch.int32, device=dev) for _ in range(n_buf)]
     rgba = rgbas[0]
@@ -251,13 +265,13 @@ def main():
         if overlap and ev_gather[k] is not None:
             stream.wait_event(ev_gather[k])          # the gather that last read this buffer is done
         pt.launch_kernel((accum if into is None else into).data_ptr(), buf.data_ptr(), cam, p, spp)
-        if world == 1:
+        if not use_dist:
             return
         if overlap:
             ev_render[k].record(stream)
             with torch.cuda.stream(side):
                 side.wait_event(ev_render[k])
-                staging[k] = tile_split.gather_stripes(buf, layout, dst=0, staging=staging[k])
+                staging[k] = tile_split.gather_stripes(buf, layout, dst=0, staging=staging[k], force=a.force_dist)
                 ev_gather[k] = torch.cuda.Event()
                 ev_gather[k].record(side)
                 buf.record_stream(side)
@@ -273,7 +287,7 @@ def main():
         return rgbas[(step_no[0] - 1) % n_buf]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -283,10 +297,10 @@ def main():
         for k in range(n_steps):
             step(first + k, params, spp=spp, fresh=fresh)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -331,6 +345,13 @@ def main():
     def rate(n_steps, seconds, spp=a.spp):
         return round(rays_per_step / a.spp * spp * n_steps / seconds / 1e6, 1)
 
+    def settle(params=base, spp=a.spp):
+        """untimed calls in front of a side measurement: PT_KERNEL_AUTO's two trial calls, its decision, and the
+        buffers either stage layout allocates on first use"""
+        for k in range(4):
+            step(k, params, spp=spp)
+        torch.cuda.synchronize()
+
     extra = {}
     if not a.no_extra:
         n_x = max(5, a.steps // 5)
@@ -339,24 +360,24 @@ def main():
                 continue
             pm = g.Params.from_buffer_copy(base)
             pm.tri_mat = m
-            step(0, pm)
+            settle(pm)
             extra[f"mrays_per_s_{name}"] = round(W * H * a.depth * a.spp * n_x / timed(n_x, 1, pm) / 1e6, 1)
         # the reference's own granularity: ONE sample per launch (BasicScene.cpp:395-404), sync between launches
         # not needed (in-order stream)
-        step(0, spp=1)
+        settle(spp=1)
         n_1 = max(20, a.steps)
         extra["mrays_per_s_1spp"] = rate(n_1, timed(n_1, 1, spp=1), spp=1)
         if world == 1:
             for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT)):
                 pt.set_option(g.OPT_KERNEL, kern)
-                step(0)
+                settle()
                 extra[f"mrays_per_s_{kname}"] = rate(n_x, timed(n_x, 1))
-                step(0, spp=1)
+                settle(spp=1)
                 extra[f"mrays_per_s_1spp_{kname}"] = rate(n_1, timed(n_1, 1, spp=1), spp=1)
             pt.set_option(g.OPT_KERNEL, a.kernel)
 
     merged_ok = None
-    if world > 1:
+    if use_dist:
         # rank 0 re-renders the last gathered frame alone and compares the display words
         last = a.warmup + a.steps
         step(last, fresh=True)   # sample_index 1: the frame does not depend on accumulated history
@@ -384,7 +405,7 @@ def main():
                        "bvh": {"inner": info["n_inner"], "tri_refs": info["n_tri_refs"], "max_depth": info["max_depth"],
                                "device_mb": round(info["device_bytes"] / 2 ** 20, 1), "built_on": "device" if a.device_build else "host"},
                        "parallelism": (f"tile-split x{world} ({rows}-row stripes, RCCL all-gather of RGBA8 every step"
-                                       f"{', overlapped with the next render' if overlap else ''})") if world > 1 else "1 GPU",
+                                       f"{', overlapped with the next render' if overlap else ''})") if use_dist else "1 GPU",
                        "closed_scene": bool(closed), "rays_per_step": rays_per_step,
                        "tile_split_equals_single_gpu": merged_ok},
             "stage_ms": {k: round(v, 4) for k, v in stage.items() if v > 0},
@@ -490,7 +511,7 @@ def main():
         # (pt_build_bvh); done last, it replaces the scene of this context
         n_x = max(5, a.steps // 5)
         build_ms = min(pt.build_bvh(mesh) for _ in range(3))
-        step(0)
+        settle()
         out["device_bvh_build_ms"] = round(build_ms, 2)          # PLOC (the default PT_OPT_BUILD_ALGO)
         out["mrays_per_s_device_built_tree"] = rate(n_x, timed(n_x, 1))
         pt.set_option(g.OPT_BUILD_ALGO, 0)                          # Karras LBVH: the fastest build
@@ -502,7 +523,7 @@ def main():
             big = g.scene_mesh("cornell_dragon_6400k")
             b_ms = pt.build_bvh(big)
             binfo = pt.scene_info()
-            step(0)
+            settle()
             n_b = max(3, a.steps // 10)
             dtb = timed(n_b, 1)
             pt.set_option(g.OPT_TIMING, 1)
@@ -531,11 +552,12 @@ def main():
                                                     "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
                                                     "frac": round(b_items / (bst[bdom] * 1e-3) / gb["items_per_s_l2_resident"], 4)}
         except Exception as e:
-            out["big_scene"] = {"error": str(e)[:200]}
+            import traceback
+            out["big_scene"] = {"error": str(e)[:200], "where": traceback.format_exc().strip().splitlines()[-3:]}
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     pt.close()

@@ -75,6 +75,19 @@ struct pt_ctx {
         float ms[2] = {0.f, 0.f};
     } pick;
     uint64_t scene_gen = 0;      // bumped by every upload / build
+    // Overlap of consecutive calls (PT_OPT_OVERLAP, persistent / mega kernels): the path kernel of call k + 1 runs on
+    // a side stream into its own sample buffer while call k's last paths drain; only the folds (which touch the
+    // accumulator, in order) stay on the caller's stream.  side[x]: stream, sample buffer, queue counters of slot x.
+    int opt_overlap = 1;
+    struct Side {
+        hipStream_t stream = nullptr;
+        hipEvent_t traced = nullptr, folded = nullptr;   // path kernel done / the fold that read the buffer done
+        bool fold_pending = false;
+        float* samples = nullptr;
+        size_t samples_bytes = 0;
+        unsigned int* queue = nullptr;
+    } side[2];
+    int side_next = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     // PT_OPT_TIMING: events between the stages of the last call (pt_get_stage_ms); stage_kind[i] is the

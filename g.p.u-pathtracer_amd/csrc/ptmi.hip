@@ -19,8 +19,20 @@ static_assert(sizeof(pt_sphere) == 44, "pt_sphere must match the reference Spher
 static_assert(sizeof(pt_sphere_d) == sizeof(pt_sphere), "device sphere mirror");
 static_assert(sizeof(pt_params) == 104 && sizeof(pt_camera) == 64 && sizeof(pt_counters) == 48, "ABI struct sizes (tests/test_host_and_abi.py)");
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 namespace ptmi {
 thread_local std::string g_err;
+static void dbg_segv(int sig) {
+    void* bt[64];
+    const int n = backtrace(bt, 64);
+    const char msg[] = "ptmi debug: fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
 }
 using namespace ptmi;
 
@@ -61,6 +73,7 @@ int pt_create(int device, pt_ctx** out) {
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
     if (device < 0 || device >= n) return fail(nullptr, PT_ERR_INVALID, "pt_create: no such device");
     pt_ctx* c = new pt_ctx();
+    if (getenv("PT_DEBUG_SEGV")) signal(SIGSEGV, ptmi::dbg_segv);
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
@@ -88,6 +101,14 @@ int pt_destroy(pt_ctx* c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_samples);
     (void)hipFree(c->d_wave);
+    for (pt_ctx::Side& s : c->side) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        (void)hipFree(s.samples);
+        (void)hipFree(s.queue);
+        if (s.traced) (void)hipEventDestroy(s.traced);
+        if (s.folded) (void)hipEventDestroy(s.folded);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
     for (hipEvent_t e : c->stage_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->pick.e) if (e) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -152,6 +173,7 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: vote weight must be 1..64");
             (option == PT_OPT_VOTE_NODE ? c->opt_vote_node : c->opt_vote_rec) = value;
             return PT_OK;
+        case PT_OPT_OVERLAP: c->opt_overlap = value != 0; return PT_OK;
         case PT_OPT_WAVE_BLOCKS:
             if (value < 1 || value > 8) return fail(c, PT_ERR_INVALID, "pt_set_option: wave blocks must be 1..8 per CU");
             c->opt_wave_blocks = value;
@@ -489,19 +511,48 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     // spp > 1: trace the samples as independent work items, fold them afterwards (k_fold_samples); the
     // stage-split pipeline always works that way
     P.samples = nullptr;
-    if (spp > 1 || wavefront) {
-        const size_t need = (size_t)spp * (size_t)p->width * (size_t)p->height * 3 * sizeof(float);
-        if (need > c->samples_bytes) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_samples);
-            c->d_samples = nullptr;
-            c->samples_bytes = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->d_samples, need));
-            c->samples_bytes = need;
+    // overlap with the previous call: the path kernel goes to a side stream with its own sample buffer and queue
+    // counters, so it can start while the previous call's last paths drain (the tail of a call is as long as its
+    // longest path: ~15 % of a one-sample 1080p call); instrumented, timed and trial calls run in line
+    pt_ctx::Side* sd = nullptr;
+    if (c->opt_overlap && !wavefront && !c->opt_counters && !c->opt_timing && probe < 0) {
+        sd = &c->side[c->side_next];
+        c->side_next ^= 1;
+        if (!sd->stream) {
+            // a priority of its own: ROCm maps the streams of one priority onto a few hardware queues round-robin (four
+            // by default, GPU_MAX_HW_QUEUES), and a side stream that shares a hardware queue with the caller's stream or
+            // with the other side stream runs in order behind it — no overlap and a 5-9 % LOSS (measured with a second
+            // context alive).  The high-priority class has queues of its own.
+            int prio_lo = 0, prio_hi = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            HIP_TRY(c, hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio_hi));
+            HIP_TRY(c, hipEventCreateWithFlags(&sd->traced, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&sd->folded, hipEventDisableTiming));
+            HIP_TRY(c, hipMalloc((void**)&sd->queue, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int)));
         }
-        P.samples = c->d_samples;
+    }
+    if (spp > 1 || wavefront || sd) {
+        const size_t need = (size_t)spp * (size_t)p->width * (size_t)p->height * 3 * sizeof(float);
+        float*& buf = sd ? sd->samples : c->d_samples;
+        size_t& have = sd ? sd->samples_bytes : c->samples_bytes;
+        if (need > have) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));   // every path kernel has a fold behind it on this stream
+            (void)hipFree(buf);
+            buf = nullptr;
+            have = 0;
+            HIP_TRY(c, hipMalloc((void**)&buf, need));
+            have = need;
+        }
+        P.samples = buf;
     }
     const int work_tiles = P.n_tiles * (P.samples ? (int)spp : 1);
+    // the stream the path kernel runs on: it may start once the caller's earlier work has been SUBMITTED, needs the
+    // scene only, and must not overwrite its sample buffer before the fold that last read it is done
+    hipStream_t trace_stream = c->stream;
+    if (sd) {
+        trace_stream = sd->stream;
+        if (sd->fold_pending) HIP_TRY(c, hipStreamWaitEvent(sd->stream, sd->folded, 0));
+    }
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe], c->stream));
@@ -534,7 +585,8 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         P.refill = c->opt_refill < c->opt_batch ? c->opt_refill : c->opt_batch;
         P.vote_node = c->opt_vote_node;
         P.vote_rec = c->opt_vote_rec;
-        HIP_TRY(c, hipMemsetAsync(c->d_queue, 0, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int), c->stream));
+        if (sd) P.queue = sd->queue;
+        HIP_TRY(c, hipMemsetAsync(P.queue, 0, PT_SHARDS * PT_SHARD_STRIDE * sizeof(unsigned int), trace_stream));
     }
     // queue granularity: 64-slot chunks when the launch has plenty of them per resident wave, smaller
     // ones for small launches (an eighth of a 1080p frame per GPU is ~4 000 tiles for ~5 000 waves)
@@ -555,15 +607,23 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         const int rc = render_wavefront(c, P, L, work_tiles);
         if (rc != PT_OK) return rc;
     } else if (persistent) {
-        HIP_TRY(c, launch_persist(L, P, c->stream));
+        HIP_TRY(c, launch_persist(L, P, trace_stream));
         if (stage_mark(c, PT_STAGE_FRAME) != PT_OK) return PT_ERR_DEVICE;
     } else {
-        HIP_TRY(c, launch_mega(L, P, c->stream));
+        HIP_TRY(c, launch_mega(L, P, trace_stream));
         if (stage_mark(c, PT_STAGE_FRAME) != PT_OK) return PT_ERR_DEVICE;
+    }
+    if (sd) {   // the fold (accumulator, display words) waits for the path kernel on the caller's stream
+        HIP_TRY(c, hipEventRecord(sd->traced, sd->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, sd->traced, 0));
     }
     if (P.samples) {
         HIP_TRY(c, launch_fold(P, c->stream));
         if (stage_mark(c, PT_STAGE_FOLD) != PT_OK) return PT_ERR_DEVICE;
+    }
+    if (sd) {
+        HIP_TRY(c, hipEventRecord(sd->folded, c->stream));
+        sd->fold_pending = true;
     }
     if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe + 1], c->stream));
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }

@@ -43,7 +43,7 @@ class StripeLayout:
         return frame.view(self.stripes_per_rank, self.world, per)
 
 
-def gather_stripes(frame, layout, dst=0, group=None, staging=None):
+def gather_stripes(frame, layout, dst=0, group=None, staging=None, force=False):
     """Collect every rank's stripes of `frame` into rank `dst`'s copy of `frame` (in place).
 
     GPU tensors: one all_gather_into_tensor (RCCL all-gather: 1/world of the frame per rank,
@@ -51,7 +51,7 @@ def gather_stripes(frame, layout, dst=0, group=None, staging=None):
     CPU tensors (gloo tests / rehearsal): dist.gather + per-rank copies.
     Runs on the CURRENT stream: call it under `torch.cuda.stream(side)` to overlap it with the
     next frame's render.  Returns the staging tensors so callers in a timed loop reuse them."""
-    if layout.world == 1:
+    if layout.world == 1 and not force:   # force: a one-rank group still goes through the collective (bench --force-dist)
         return staging
     view = layout.frame_view(frame)
     if frame.is_cuda:

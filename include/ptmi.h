@@ -144,6 +144,11 @@ enum {
     PT_OPT_WAVE_BLOCKS = 19,  /* PT_KERNEL_WAVEFRONT, extend stage: resident 256-thread blocks per CU its persistent grid is
                                  sized for, 1..8 (default 8 = 8 waves per SIMD); fewer leave room for another
                                  context's launches on the same device                                 */
+    PT_OPT_OVERLAP = 21,      /* 1 (default): the path kernel of a pt_render call (persistent / mega kernels) runs on a
+                                 stream of the context's own, so that it can start while the PREVIOUS call's last paths
+                                 drain; the fold into the accumulator stays on the caller's stream, in call order.  A
+                                 host that syncs before every launch (as BasicScene.cpp:395 does) sees no difference;
+                                 0 = everything on the caller's stream                                          */
     PT_OPT_BUILD_ALGO = 16,   /* pt_build_bvh: 1 (default) = PLOC (locally-ordered clustering over Morton order:
                                  a tree as good as the host SAH/SBVH builder's, ~6.5 ms for 800 k triangles;
                                  degenerate input falls back to 0), 0 = LBVH (Karras hierarchy: 1.8 ms, a

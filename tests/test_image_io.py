@@ -123,3 +123,22 @@ def test_app_device_build_gives_the_same_picture(tmp_path):
     run(["--device-build", "--fix-estimators", "--out", str(tmp_path / "fix.pfm")])
     c = read_pfm(tmp_path / "fix.pfm")
     assert np.isfinite(c).all() and np.any(c != b)
+
+
+@pytest.mark.gpu
+def test_app_tile_split_over_contexts_is_bit_identical(tmp_path):
+    """pt_app --gpus N --tile R (one context per GPU, here all on the one device; stripes gathered on the host for
+    the PFM, the PNG and the checkpoint) == the unsplit run, bit for bit: SURVEY.md §8e from a C++ host."""
+    mesh = os.path.join(ROOT, "assets", "gto_sixteen.ptmesh")
+    common = [APP, "--mesh", mesh, "--width", "401", "--height", "233", "--frames", "5", "--spp", "2"]
+    run = lambda extra: subprocess.run(common + extra, check=True, capture_output=True, text=True, timeout=300).stdout
+    run(["--out", str(tmp_path / "one.pfm")])
+    out = run(["--gpus", "3", "--tile", "16", "--out", str(tmp_path / "three.pfm"), "--checkpoint", str(tmp_path / "three.ckpt")])
+    assert "tile split over 3 context(s)" in out
+    one, three = read_pfm(tmp_path / "one.pfm"), read_pfm(tmp_path / "three.pfm")
+    assert np.array_equal(one, three) and one.mean() > 0.005
+    acc, nf, cp, _ = g.load_checkpoint(str(tmp_path / "three.ckpt"))
+    assert (nf, cp) == (5, 5) and np.array_equal(acc, one)
+    run(["--gpus", "2", "--out", str(tmp_path / "two.png")])
+    run(["--out", str(tmp_path / "one.png")])
+    assert np.array_equal(decode_png(tmp_path / "two.png"), decode_png(tmp_path / "one.png"))
