@@ -417,49 +417,54 @@ def main():
         dom = max((k for k in ("frame", "extend", "shade") if stage.get(k, 0) > 0), key=lambda k: stage[k], default=None)
         launches = a.depth if dom in ("extend", "shade") else 1
         kname = {"frame": "k_trace_persist_bvh2" if a.kernel != 1 else "k_trace_mega_bvh2", "extend": "k_wf_extend", "shade": "k_wf_shade"}.get(dom)
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": kname, "launches_per_step": launches}
+        roof = {"bound": "hbm", "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": kname, "launches_per_step": launches, "hbm_peak": HBM_PEAK_GBS}
         if world == 1 and dom:
             kms = stage[dom] / launches
             roof["kernel_ms_avg"] = round(kms, 4)
-            # (1) what the kernel REQUESTS from the memory system per launch: 64-byte items (node or record) the walk
-            #     fetches, counted by the instrumented replay, + its streams (wavefront: 32-B ray in, 8-B hit out;
-            #     persistent: 12 B sample colour out per path)
+            # ACHIEVED = the bytes this kernel's algorithm moves per launch / its HIP-event duration.  Per unit:
+            # 64 B per item the walk fetches (wide node or triangle record, counted by the instrumented replay) + the
+            # kernel's own streams (extend: 32-B ray in, 8-B hit out per segment; persistent: 12-B sample colour per path).
             items = (items_nodes + items_recs) / launches
             stream_b = (rays_per_step * 40.0 / launches) if dom == "extend" else (12.0 * paths_per_step)
             req = items * 64.0 + stream_b
-            roof["requested"] = {"bytes_per_launch": int(req), "gbs": round(req / (kms * 1e-3) / 1e9, 1),
-                                 "items_per_ray": round((items_nodes + items_recs) / rays_per_step, 2),
-                                 "gitems_per_s": round(items / (kms * 1e-3) / 1e9, 2),
-                                 "note": "64 B x (wide nodes + triangle records fetched) + the kernel's own streams; served by L2 / "
-                                         "Infinity Cache when the scene fits them"}
+            roof["achieved"] = round(req / (kms * 1e-3) / 1e9, 1)
+            roof["bytes_per_launch"] = int(req)
+            roof["items_per_ray"] = round((items_nodes + items_recs) / rays_per_step, 2)
+            roof["gitems_per_s"] = round(items / (kms * 1e-3) / 1e9, 2)
             if wstats:
                 roof["lane_use"] = {"node_steps": round(wstats["act_node"] / max(1, 64 * wstats["it_node"]), 3),
                                     "record_steps": round(wstats["act_rec"] / max(1, 64 * wstats["it_rec"]), 3),
                                     "stack_overflows_per_ray": round(wstats["stack_overflows"] / max(1.0, rays_per_step), 4)}
-            # (2) the bound that CAN bind it: dependent random 64-byte gathers over a table of the scene's size
+            # PEAK = what binds a per-lane walk whose scene sits in the caches: the rate at which the memory hierarchy serves
+            # DEPENDENT random 64-byte items to every lane of 8 waves/SIMD when every fetch is an L2 hit (tools/ubench_gather,
+            # run here as a child process: 2 MB table), x 64 B.  The HBM figures (8 TB/s spec) are quoted beside it: this
+            # 105 MB scene never reaches HBM for its items, only for the ray / hit streams.
             if not a.no_extra:
                 try:
                     gb = gather_bound(info["device_bytes"])
                 except Exception as e:
                     gb = {"error": str(e)[:100]}
                 if gb and "items_per_s" in gb:
+                    roof["peak"] = round(gb["items_per_s_l2_resident"] * 64.0 / 1e9, 1)
+                    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
                     roof["gather_bound"] = {"gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
                                             "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
                                             "table_mb": round(gb["table_bytes"] / 2 ** 20, 1),
-                                            "frac": round(items / (kms * 1e-3) / gb["items_per_s_l2_resident"], 4),
-                                            "note": "tools/ubench_gather (child process): every lane of 8 waves/SIMD chases random 64-B items; "
-                                                    "l2_resident (2 MB table: every fetch an L2 hit) is the ceiling of ANY per-lane walk, "
-                                                    "uniform_over_scene is a walk with no locality at all; frac = this kernel's item rate / the ceiling"}
-            # (3) HBM-side traffic per launch from rocprofv3 --pmc passes: only quoted when collected for THIS source
+                                            "note": "every lane of 8 waves/SIMD chases random 64-B items: through a 2 MB table (every fetch an "
+                                                    "L2 hit: the ceiling of ANY per-lane walk = peak) and through a table of the scene's size "
+                                                    "(a walk with no locality at all)"}
+            # HBM-side traffic per launch from rocprofv3 --pmc passes: only quoted when collected for THESE kernel sources
             tr = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
             if os.path.exists(tr):
                 try:
                     j = json.load(open(tr))
-                    w = j.get("workloads", {}).get(f"{a.scene}/{KERNEL_NAMES.get(a.kernel, a.kernel)}/{a.spp}spp")
-                    if j.get("source_sha") == source_sha() and w and w.get("kernel") == kname:
+                    w = j.get("kernels", {}).get(kname)
+                    if j.get("source_sha") == source_sha() and w and (a.scene, W, H, a.spp) == ("cornell_dragon_800k", 1920, 1080, 16):
                         roof["traffic"] = w.get("hbm_bytes_per_launch")
-                        roof["traffic_source"] = "profiles/r02_pmc_traffic.json (same kernel sources)"
+                        roof["hbm_measured"] = {"gbs": round(w["hbm_bytes_per_launch"] / (kms * 1e-3) / 1e9, 1),
+                                                "frac_of_hbm_peak": round(w["hbm_bytes_per_launch"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources)"}
                 except Exception:
                     pass
         if world == 1 and a.cpu_frames > 0:
@@ -479,24 +484,21 @@ def main():
                              "max_abs": float(np.abs(diff).max()),
                              "what": f"GPU accumulator after {a.cpu_frames} timed-configuration step(s) vs oracle/pt_oracle.c, same seeds"}
             if dom:
-                # SURVEY 8(d) ALGORITHMIC bytes (reference layout: 64 B per binary node, 48 B per triangle, 16 B per
-                # leaf, 4 B per hit, 44 B per sphere, 28 B per pixel-sample), counted by the oracle on the reference's
-                # own Compact arrays.  The walk part is priced against the walk kernel, everything against the step.
+                # SURVEY 8(d)'s figure, kept beside: ALGORITHMIC bytes of the REFERENCE layout (64 B per binary node, 48 B per
+                # triangle, 16 B per leaf, 4 B per hit, 44 B per sphere, 28 B per pixel-sample), counted by the oracle on the
+                # reference's own Compact arrays, over the whole step and over the HBM spec peak.  The caches serve these
+                # bytes, so the quotient is not bounded by 1.
                 alg_step = g.algorithmic_bytes(cnt, n_sph) / a.cpu_frames
-                alg_walk = (64 * cnt["inner"] + 48 * cnt["tris"] + 16 * cnt["leaves"] + 4 * cnt["hits"]) / a.cpu_frames
                 step_ms = sum(v for k, v in stage.items() if k != "none")
-                alg_launch = (alg_walk if dom == "extend" else alg_step) / launches
-                roof["achieved"] = round(alg_launch / (stage[dom] / launches * 1e-3) / 1e9, 1)
-                roof["frac"] = round(roof["achieved"] / HBM_PEAK_GBS, 4)
-                roof["algorithmic"] = {"bytes_per_launch": int(alg_launch), "bytes_per_step": int(alg_step),
-                                       "bytes_per_ray": round(alg_step / (cnt["rays"] / a.cpu_frames), 1),
-                                       "nodes_per_ray": round(cnt["inner"] / cnt["rays"], 2), "tris_per_ray": round(cnt["tris"] / cnt["rays"], 2),
-                                       "gbs_whole_step": round(alg_step / (step_ms * 1e-3) / 1e9, 1)}
-                roof["note"] = ("achieved/frac follow SURVEY 8d: ALGORITHMIC bytes of the reference layout per launch of the dominant "
-                                "kernel / its HIP-event duration / 8 TB/s.  The 105 MB scene sits in L2 + Infinity Cache, so this figure is "
-                                "not bounded by HBM (frac may exceed 1); 'requested' is what this kernel really fetches, 'gather_bound.frac' "
-                                "(<= 1) prices it against the measured gather rate of the cache hierarchy, 'traffic' is the measured "
-                                "HBM-side bytes when a PMC profile of these sources is committed; big_scene repeats it beyond the Infinity Cache.")
+                roof["algorithmic_8d"] = {"bytes_per_step": int(alg_step), "bytes_per_ray": round(alg_step / (cnt["rays"] / a.cpu_frames), 1),
+                                          "nodes_per_ray": round(cnt["inner"] / cnt["rays"], 2), "tris_per_ray": round(cnt["tris"] / cnt["rays"], 2),
+                                          "gbs_whole_step": round(alg_step / (step_ms * 1e-3) / 1e9, 1),
+                                          "over_hbm_peak": round(alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        roof["note"] = ("achieved = bytes the dominant kernel's walk requests per launch (items x 64 B + its streams) / its HIP-event duration; "
+                        "peak = the measured rate of dependent 64-B gathers when every fetch hits L2 (the bound that can bind a walk over a "
+                        "cache-resident scene), so frac <= 1; hbm_peak = 8 TB/s spec, hbm_measured = PMC traffic of these kernel sources; "
+                        "algorithmic_8d = SURVEY 8(d)'s reference-layout bytes over the whole step, which caches serve (may exceed the HBM peak); "
+                        "big_scene repeats the exercise with a 1.2 GB item buffer that does not fit the Infinity Cache")
         out["roofline"] = roof
         if world == 1 and not a.no_cpu_reference:
             try:

@@ -26,4 +26,5 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" \
     echo "pmc pass $i done: $SET" | tee -a "$OUT/progress.txt"
 done
 python3 "$R/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
+python3 "$R/tools/pmc_traffic.py" "$OUT" "$OUT/pmc_traffic.json" > /dev/null 2>&1
 cat "$OUT/summary.txt"
