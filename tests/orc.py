@@ -1,7 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/liborc.so) — TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module;
-nothing under g.p.u-pathtracer_amd/ does (tests/test_layout.py enforces it).
+nothing under g.p.u-pathtracer_amd/ does (tests/test_host_and_abi.py::test_product_never_touches_the_oracle enforces it).
 """
 import ctypes as C
 import os

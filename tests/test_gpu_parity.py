@@ -348,3 +348,36 @@ def test_error_handling(pt):
     nodes.view(np.int32)[3, 0] = ~5000                                # leaf past the array
     with pytest.raises(g.PtError):
         pt.upload_bvh_arrays(nodes.ctypes.data, 16, bvh.tris.ctypes.data, 101, bvh.index.ctypes.data, 101)
+
+
+def test_bad_triangle_ids_and_oversized_calls_are_refused():
+    """pt_upload_bvh rejects triangle ids the kernels cannot carry (-1 is the walks' miss marker, ids index the material
+    rows); pt_render refuses width*height*spp >= 2^31 BEFORE touching its buffers, so the context keeps working."""
+    _, bvh = bvh_of("cornell")
+    t = g.PathTracer(0)
+    try:
+        bad = type("B", (), {})()
+        bad.nodes, bad.tris, bad.index = bvh.nodes, bvh.tris, bvh.index.copy()
+        first = int(np.flatnonzero(bad.index >= 0)[0])
+        for v in (-1, -7, 1 << 30):
+            bad.index[first] = v
+            with pytest.raises(g.PtError) as e:
+                t.upload_bvh(bad)
+            assert e.value.code == -1 and "triangle id" in str(e.value)
+        t.upload_bvh(bvh)
+        t.upload_spheres(g.reference_spheres())
+        W, H = 640, 360
+        cam, p = golden_camera(W, H), g.default_params(W, H)
+        acc, rgba = t.alloc_frame(W, H)
+        t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 2)
+        t.sync()
+        before = acc.download(np.float32, (H, W, 3))
+        with pytest.raises(g.PtError) as e:
+            t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 20000)     # 640*360*20000 >= 2^31
+        assert e.value.code == -1 and "too large" in str(e.value)
+        acc.zero()
+        t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 2)             # the context is intact
+        t.sync()
+        assert np.array_equal(acc.download(np.float32, (H, W, 3)), before)
+    finally:
+        t.close()

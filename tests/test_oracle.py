@@ -254,3 +254,31 @@ def test_partition_is_bit_identical():
         p.part_index, p.part_count, p.part_rows = part, 3, 8
         orc.render(bvh, sph, cam, p, spp=2, accum=merged)
     assert np.array_equal(full, merged)
+
+
+def test_config1_cornell_256_through_the_reference_cpu_tracer(tmp_path):
+    """BASELINE.json configs[0], literally: cornell.obj 256x256 1 spp through the reference's own CpuRayTracer classes on
+    the host CPU (oracle/_ref = Scene / Mesh / KDNode / Material compiled from /root/reference; plumbing, no GPU).  The
+    render loop is renderer.cpp:197-222's, the room main.cpp:26-35's; every camera ray is one path, the segment counter
+    sits in front of the mesh (a forwarding Object), and the image is finite and lit."""
+    import json
+    import subprocess
+    if not os.path.exists(orc.REF_BIN):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    mesh = g.scene_mesh("cornell")
+    v, f = mesh.verts.astype(np.float64), mesh.tris
+    lo, hi = v.min(0), v.max(0)
+    v = (v - 0.5 * (lo + hi)) * (3.0 / float(np.max(hi - lo)))     # into the room: 3 units, z-up, on the floor
+    v = np.stack([v[:, 0], -v[:, 2], v[:, 1]], -1)
+    v[:, 2] -= v[:, 2].min()
+    obj, out = tmp_path / "cornell.obj", tmp_path / "img.f32"
+    with open(obj, "w") as fh:
+        fh.write("o cornell\n")
+        np.savetxt(fh, v, fmt="v %.6f %.6f %.6f")
+        np.savetxt(fh, f + 1, fmt="f %d %d %d")
+    r = subprocess.run([orc.REF_BIN, "render", str(obj), "256", "256", "1", "0", "0", "0", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-300:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    img = np.fromfile(out, np.float32).reshape(256, 256, 3)
+    assert j["paths"] == 256 * 256 and j["segments"] >= j["paths"]
+    assert np.isfinite(img).all() and 0.05 < img.mean() < 2.2 and abs(img.mean() - j["mean"]) < 1e-4
