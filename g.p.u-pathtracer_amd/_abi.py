@@ -74,6 +74,7 @@ FLAG_METAL_LITERAL_W = 1 << 0
 FLAG_WRITE_RGBA = 1 << 1
 FLAG_FACE_FORWARD, FLAG_COSINE_DIFF, FLAG_GLASS_FIX, FLAG_RUSSIAN_ROULETTE, FLAG_MISS_KEEPS_PATH = 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6
 FLAG_RR_CPU_TRACER = 1 << 7
+FLAG_NEE = 1 << 8
 FLAGS_SMALLPT = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RUSSIAN_ROULETTE | FLAG_MISS_KEEPS_PATH
 FLAGS_CPU_TRACER = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RR_CPU_TRACER | FLAG_MISS_KEEPS_PATH
 KERNEL_AUTO, KERNEL_MEGA_BVH2, KERNEL_MEGA_WIDE, KERNEL_PERSISTENT, KERNEL_ROLE_SPLIT, KERNEL_WAVEFRONT = 0, 1, 2, 3, 4, 5

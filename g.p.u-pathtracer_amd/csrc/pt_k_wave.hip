@@ -216,17 +216,21 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
 template <bool COUNT>
 __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
+    __shared__ int s_cnt2[PT_BLOCK / 64];
     wf_sphere_table();
     const int n_in = P.wf.cnt_in[blockIdx.x];
     const bool last = P.wf.bounce + 1 >= P.depth;
     if (n_in == 0) {
         if (!last && threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = 0;
+        if (P.wf.nee && threadIdx.x == 0) P.wf.s_cnt[blockIdx.x] = 0;
         return;
     }
     const bool have = (int)threadIdx.x < n_in;
     const size_t i = (size_t)blockIdx.x * PT_REGION + threadIdx.x;
     bool alive = false, tri_hit = false;
     PathState ps;
+    NeeReq req;
+    req.want = false;
     uint32_t pix = 0, s_idx = 0;
     if (have) {
         const float4 a = P.wf.ray0_in[i], b = P.wf.ray1_in[i];
@@ -234,6 +238,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
         ps.o = V3(a.x, a.y, a.z);
         ps.d = V3(a.w, b.x, b.y);
         pix = __float_as_uint(b.z);
+        ps.nee_mask = 0;
+        if (P.wf.nee) { ps.nee_mask = pix >> 24; pix &= 0xffffffu; }
         const uint32_t sn = __float_as_uint(b.w);
         s_idx = sn >> 12;
         ps.mask = V3(1.f, 1.f, 1.f);
@@ -265,7 +271,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             }
         } else {
             v3 col;
-            const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0);
+            const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0, P.wf.nee ? &req : nullptr);
             const v3 e = done ? col : ps.accu;   // mask * emission of this hit (accu entered as 0)
             if (!(e.x == 0.f) || !(e.y == 0.f) || !(e.z == 0.f)) {
                 smp[0] += e.x; smp[1] += e.y; smp[2] += e.z;
@@ -280,18 +286,45 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             atomicAdd(&P.counters[5], (unsigned long long)np);
         }
     }
+    if (P.wf.nee) {   // PT_FLAG_NEE: the shadow rays of this bounce's DIFF hits, packed like the survivors
+        int n_sh;
+        const int rs = wf_block_rank(req.want, n_sh, s_cnt2);
+        if (req.want) {
+            const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)rs;
+            P.wf.s_ray0[j] = make_float4(req.o.x, req.o.y, req.o.z, req.d.x);
+            P.wf.s_ray1[j] = make_float4(req.d.y, req.d.z, __uint_as_float(pix), __uint_as_float(s_idx));
+            P.wf.s_con[j] = make_float4(req.contrib.x, req.contrib.y, req.contrib.z, req.t_max);
+        }
+        if (threadIdx.x == 0) P.wf.s_cnt[blockIdx.x] = n_sh;
+    }
     if (last) return;   // every path ends with this bounce (tracer.cu:305)
     int total;
     const int r = wf_block_rank(alive, total, s_cnt);
     if (alive) {
         const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)r;
         P.wf.ray0_out[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(pix), __uint_as_float((s_idx << 12) | ps.rng.n));
+        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(P.wf.nee ? (pix | (ps.nee_mask << 24)) : pix),
+                                       __uint_as_float((s_idx << 12) | ps.rng.n));
         P.wf.mask_out[j] = ps.mask.x;
         P.wf.mask_out[(size_t)P.wf.cap + j] = ps.mask.y;
         P.wf.mask_out[2 * (size_t)P.wf.cap + j] = ps.mask.z;
     }
     if (threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = total;
+}
+
+// PT_FLAG_NEE: adds the contribution of every shadow ray that reached its light (nothing closer than t_max) to its path's
+// sample colour — after the emission this bounce's shade launch added, as the oracle orders the two sums.
+__global__ void __launch_bounds__(PT_BLOCK) k_wf_resolve(const KParams P) {
+    const int n_in = P.wf.s_cnt[blockIdx.x];
+    if ((int)threadIdx.x >= n_in) return;
+    const size_t i = (size_t)blockIdx.x * PT_REGION + threadIdx.x;
+    const float4 c = P.wf.s_con[i];
+    const float2 hh = P.wf.s_hit[i];
+    if (hh.x < c.w) return;   // a triangle is in the way
+    const float4 b = P.wf.s_ray1[i];
+    const uint32_t pix = __float_as_uint(b.z), s_idx = __float_as_uint(b.w);
+    float* smp = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+    smp[0] += c.x; smp[1] += c.y; smp[2] += c.z;
 }
 
 namespace ptmi {
@@ -306,8 +339,10 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     // carve: [ray0 x2][ray1 x2][mask x2 (3 planes)][hit][cnt x2][hashes][queues]
     const size_t b_ray = cap * 16, b_mask = cap * 12, b_hit = cap * 8, b_cnt = ((n_regions * 4 + 255) / 256) * 256;
     const size_t b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
-    const size_t q_words = (size_t)P.depth * PT_SHARDS * PT_SHARD_STRIDE, b_q = q_words * 4;
-    const size_t need = 4 * b_ray + 2 * b_mask + b_hit + 2 * b_cnt + b_hash + b_q;
+    const bool nee = (P.flags & PT_FLAG_NEE) != 0;
+    const size_t q_words = (size_t)P.depth * (nee ? 2 : 1) * PT_SHARDS * PT_SHARD_STRIDE, b_q = q_words * 4;
+    const size_t b_nee = nee ? 3 * b_ray + b_hit + b_cnt : 0;   // shadow records: s_ray0, s_ray1, s_con, s_hit, s_cnt
+    const size_t need = 4 * b_ray + 2 * b_mask + b_hit + 2 * b_cnt + b_hash + b_q + b_nee;
     if (need > c->wave_bytes) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_wave);
@@ -329,6 +364,15 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     unsigned long long* hashes = (unsigned long long*)base;
     base += b_hash;
     unsigned int* queues = (unsigned int*)base;
+    base += b_q;
+    P.wf.nee = nee ? 1 : 0;
+    if (nee) {
+        P.wf.s_ray0 = (float4*)base;
+        P.wf.s_ray1 = (float4*)(base + b_ray);
+        P.wf.s_con = (float4*)(base + 2 * b_ray);
+        P.wf.s_hit = (float2*)(base + 3 * b_ray);
+        P.wf.s_cnt = (int*)(base + 3 * b_ray + b_hit);
+    }
 
     hipStream_t st = c->stream;
     P.sc.n_top = 0;
@@ -367,13 +411,27 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
         } while (0)
         if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24); else PT_EXT(true, 8, 16); }
         else { if (L.lstk == 24) PT_EXT(false, 6, 24); else PT_EXT(false, 8, 16); }
-#undef PT_EXT
         if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
         if (L.count) hipLaunchKernelGGL(k_wf_shade<true>, dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P);
         else hipLaunchKernelGGL(k_wf_shade<false>, dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P);
         HIP_TRY(c, hipGetLastError());
         if (stage_mark(c, PT_STAGE_SHADE) != PT_OK) return PT_ERR_DEVICE;
+        if (nee) {   // this bounce's shadow rays: the same extend kernel over the shadow records, then the resolve
+            KParams S = P;
+            S.wf.ray0_in = P.wf.s_ray0; S.wf.ray1_in = P.wf.s_ray1; S.wf.cnt_in = P.wf.s_cnt; S.wf.hit = P.wf.s_hit;
+            S.wf.queue = queues + ((size_t)P.depth + b) * PT_SHARDS * PT_SHARD_STRIDE;
+            const KParams keep = P;
+            P = S;
+            if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24); else PT_EXT(true, 8, 16); }
+            else { if (L.lstk == 24) PT_EXT(false, 6, 24); else PT_EXT(false, 8, 16); }
+            P = keep;
+            if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
+            hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)n_regions), dim3(PT_BLOCK), 0, st, P);
+            HIP_TRY(c, hipGetLastError());
+            if (stage_mark(c, PT_STAGE_SHADE) != PT_OK) return PT_ERR_DEVICE;
+        }
     }
+#undef PT_EXT
     return PT_OK;
 }
 

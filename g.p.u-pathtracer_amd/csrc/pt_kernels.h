@@ -59,6 +59,14 @@ struct KWave {
     uint32_t queues_words;
     uint32_t cap;                 // slots per plane (regions * 256)
     int n_regions;
+    // PT_FLAG_NEE: the shadow-ray records a shade launch emits (region-compacted like the survivors), traced by another
+    // extend launch and resolved by k_wf_resolve: s_ray0/s_ray1 as ray0/ray1, s_con = (contribution rgb, t_max), s_hit
+    float4* __restrict__ s_ray0;
+    float4* __restrict__ s_ray1;
+    float4* __restrict__ s_con;
+    float2* __restrict__ s_hit;
+    int* __restrict__ s_cnt;
+    int nee;                      // 1: ray1.z carries pixel | nee_mask << 24
     uint32_t bounce;
 };
 
@@ -158,7 +166,37 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
             }
         }
         if (COUNT) { n_rays++; n_hits += (h.tri != -1); }
-        if (path_shade(P, ps, h, col)) break;
+        NeeReq req;
+        req.want = false;
+        const bool done = path_shade(P, ps, h, col, -1, (P.flags & PT_FLAG_NEE) ? &req : nullptr);
+        // the loop's exit condition crosses the shadow walk below in a VGPR: kept as a lane mask in SGPRs, hipcc (ROCm 7.2)
+        // lost it across the walk's wave-uniform loop and a finished path ran one more bounce
+        int done_v = done ? 1 : 0;
+        asm volatile("" : "+v"(done_v));
+        if (req.want) {   // PT_FLAG_NEE: the shadow ray of this DIFF hit, against the triangles
+            Hit h2;
+            h2.t = PT_F32_MAX; h2.tri = -1; h2.rec = 0;
+            if (P.sc.has_bvh) {
+                TravState ts;
+                if (ALG >= 2) {
+                    trav_begin(ts, req.o, req.d, stk, P.sc.wide_root);
+                    trav_run_wide<COUNT, false, ALG == 3, STK>(ts, P.sc, req.o, req.d, cull, stk, tc, 0, 0);
+                } else if (ALG == 1) {
+                    trav_begin(ts, req.o, req.d, stk);
+                    trav_run_unified<COUNT, false, STK>(ts, P.sc, req.o, req.d, cull, stk, tc, 0, 0);
+                } else {
+                    trav_begin(ts, req.o, req.d, stk);
+                    trav_run<COUNT, false, true, STK>(ts, P.sc, req.o, req.d, cull, stk, tc, 0, 0, s_top);
+                }
+                h2 = ts.h;
+            }
+            if (COUNT) n_rays++;
+            if (!(h2.t < req.t_max)) {
+                ps.accu = vadd(ps.accu, req.contrib);
+                if (done) col = vadd(col, req.contrib);   // the path ended with this bounce: col was the gathered light before it
+            }
+        }
+        if (done_v) break;
     }
     return col;
 }

@@ -9,6 +9,16 @@ struct PathState {
     v3 o, d, mask, accu;
     uint32_t depth;
     pt_rng rng;
+    uint32_t nee_mask;   // PT_FLAG_NEE: spheres whose light the previous bounce already sampled with a shadow ray
+};
+
+// PT_FLAG_NEE: the shadow ray a DIFF hit asks for.  The caller traces it against the triangles (the spheres in its way
+// have been tested already) and, when nothing is hit closer than t_max, adds `contrib` to the path's gathered light.
+struct NeeReq {
+    bool want;
+    v3 o, d;
+    float t_max;
+    v3 contrib;
 };
 
 // The kernel-argument block seen through an opaque pointer (constant address space, scalar loads):
@@ -37,6 +47,7 @@ __device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uin
     ps.mask = V3(1.f, 1.f, 1.f);
     ps.accu = V3(0.f, 0.f, 0.f);
     ps.depth = 0;
+    ps.nee_mask = 0;
 }
 
 // What a segment ended on once the spheres have been tested too (intersectAllSpeheres,
@@ -102,7 +113,9 @@ __device__ __forceinline__ SceneHit pt_closest_sphere(const KParams& P, v3 o, v3
 // gather instead of a global one.
 // tri_n: pt_hit_normal of the walk's triangle hit (read only when the triangle is what was hit; the
 // caller fetches it early so that the latency hides behind other work).
-__device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, const Hit& h, const SceneHit& sh, v3 tri_n, v3& col_out, int sph_tab = -1) {
+__device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, const Hit& h, const SceneHit& sh, v3 tri_n, v3& col_out, int sph_tab = -1,
+                                               NeeReq* nee = nullptr) {
+    if (nee) nee->want = false;
     PT_KARGS(K);   // shading scalars: read where they are used (see the sphere loop)
     const v3 o = ps.o, d = ps.d;
     v3 mask = ps.mask, accu = ps.accu;
@@ -151,7 +164,9 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
         if (K.flags & PT_FLAG_MISS_KEEPS_PATH) col_out = vadd(accu, vmul(mask, col_out));  // extension
         return true;
     }
-    accu = vadd(accu, vmul(mask, emit));
+    if (!(geom == 1 && sph_id < 8 && ((ps.nee_mask >> sph_id) & 1u)))   // not already gathered by a shadow ray (PT_FLAG_NEE)
+        accu = vadd(accu, vmul(mask, emit));
+    ps.nee_mask = 0;
 
     if ((K.flags & PT_FLAG_RUSSIAN_ROULETTE) && ps.depth >= 2) {  // extension
         const float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
@@ -187,6 +202,66 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
         nextdir = vnormalize(vmadd(nt, rv.z, vmadd(nl, rv.y, vscale(nb, rv.x))));
         hitpos = vmadd(nl, 0.001f, hitpos);
         mask = vmul(mask, objcol);
+        if (nee && (K.flags & PT_FLAG_NEE) && (K.flags & PT_FLAG_COSINE_DIFF)) {  // extension: next-event estimation (ptmi.h)
+            // lights = emissive spheres (of the first 8, in the kernel arguments) the point is outside of
+            typedef const __attribute__((address_space(4))) float kfloat;
+            kfloat* kp = (kfloat*)&K.ksph[0];
+            uint32_t el = 0;
+            int n_el = 0;
+#pragma unroll
+            for (int i = 0; i < PT_KSPHERES; i++) {
+                if (i < P.sc.n_spheres) {
+                    const bool lit = !(kp[11 * i + 4] == 0.0f && kp[11 * i + 5] == 0.0f && kp[11 * i + 6] == 0.0f);
+                    const v3 w = vsub(V3(kp[11 * i], kp[11 * i + 1], kp[11 * i + 2]), hitpos);
+                    if (lit && vdot(w, w) > (kp[11 * i + 3] * kp[11 * i + 3]) * 1.001f) { el |= 1u << i; n_el++; }
+                }
+            }
+            ps.nee_mask = el;
+            if (n_el > 0) {
+                const float u0 = pt_rng_next(rng), u1 = pt_rng_next(rng), u2 = pt_rng_next(rng);
+                int pick = (int)(u0 * (float)n_el);
+                if (pick > n_el - 1) pick = n_el - 1;
+                int li = 0;
+                {
+                    int k = 0;
+                    bool found = false;
+#pragma unroll
+                    for (int i = 0; i < PT_KSPHERES; i++)
+                        if (!found && ((el >> i) & 1u)) { if (k == pick) { li = i; found = true; } k++; }
+                }
+                // the picked light's attributes: per-lane index, so through a global pointer (the kernel-argument
+                // block is scalar memory)
+                const pt_sphere_d L = P.sc.spheres[li];
+                const v3 w = vsub(V3(L.px, L.py, L.pz), hitpos);
+                const float d2 = vdot(w, w), r2 = L.rad * L.rad;
+                const v3 wn = vscale(w, 1.0f / sqrtf(d2));
+                const float cos_max = sqrtf(fmaxf(0.0f, 1.0f - r2 / d2));
+                const float cos_t = 1.0f - u1 * (1.0f - cos_max);
+                const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+                float cp, sp;
+                pt_sincos2pi(u2, cp, sp);
+                v3 t1 = fabsf(wn.x) > fabsf(wn.y) ? V3(wn.z, 0.f, -wn.x) : V3(0.f, -wn.z, wn.y);
+                t1 = vnormalize(t1);
+                const v3 b1 = vnormalize(vcross(wn, t1));
+                const v3 l = vnormalize(vmadd(t1, sp * sin_t, vmadd(wn, cos_t, vscale(b1, cp * sin_t))));
+                const float cosl = vdot(nl, l);
+                const float t_light = pt_sphere_intersect(L.px, L.py, L.pz, L.rad, hitpos, l);
+                bool blocked = !(cosl > 0.0f) || t_light == 0.0f;
+                for (int j = 0; j < P.sc.n_spheres; j++) {
+                    const pt_sphere_d& sj = P.sc.spheres[j];
+                    const float ts = pt_sphere_intersect(sj.px, sj.py, sj.pz, sj.rad, hitpos, l);
+                    if (j != li && ts != 0.0f && ts < t_light && ts > 0.01f) blocked = true;
+                }
+                if (!blocked) {
+                    const float k = (cosl * (2.0f * (1.0f - cos_max))) * (float)n_el;
+                    nee->want = true;
+                    nee->o = hitpos;
+                    nee->d = l;
+                    nee->t_max = t_light;
+                    nee->contrib = vscale(vmul(mask, V3(L.emi[0], L.emi[1], L.emi[2])), k);
+                }
+            }
+        }
     } else if (mat == PT_MAT_SPEC) {  // :190-203
         nextdir = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
         hitpos = vmadd(nl, 0.001f, hitpos);
@@ -253,12 +328,12 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
 }
 
 // spheres + shading in one go (the kernels that shade in the lane that walked)
-__device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out, int sph_tab = -1) {
+__device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out, int sph_tab = -1, NeeReq* nee = nullptr) {
     // the triangle's normal is asked for NOW so that its latency hides behind the sphere tests
     v3 tri_n = V3(0.f, 0.f, 0.f);
     if (h.tri != -1) tri_n = pt_hit_normal(P.sc, h);
     const SceneHit sh = pt_closest_sphere(P, ps.o, ps.d, h, sph_tab);
-    return path_shade_hit(P, ps, h, sh, tri_n, col_out, sph_tab);
+    return path_shade_hit(P, ps, h, sh, tri_n, col_out, sph_tab, nee);
 }
 
 // running mean with per-frame clamp, tracer.cu:386-391

@@ -411,6 +411,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (p->sample_index == 0) return fail(c, PT_ERR_INVALID, "pt_render: sample_index (constantPdf) starts at 1");
     if (p->tri_mat < PT_MAT_DIFF || p->tri_mat > PT_MAT_REFR) return fail(c, PT_ERR_INVALID, "pt_render: bad triangle material");
     if ((p->flags & PT_FLAG_WRITE_RGBA) && !rgba_dev) return fail(c, PT_ERR_INVALID, "pt_render: PT_FLAG_WRITE_RGBA needs rgba_dev");
+    if ((p->flags & PT_FLAG_NEE) && !(p->flags & PT_FLAG_COSINE_DIFF)) return fail(c, PT_ERR_INVALID, "pt_render: PT_FLAG_NEE needs PT_FLAG_COSINE_DIFF (the reference's DIFF lobe has no density to weigh a light sample against)");
     if (!c->has_bvh && c->n_spheres == 0) return fail(c, PT_ERR_NO_SCENE, "pt_render: no scene uploaded");
     if (p->part_count > 1) {
         if (p->part_index < 0 || p->part_index >= p->part_count) return fail(c, PT_ERR_INVALID, "pt_render: part_index out of range");
@@ -471,7 +472,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     int probe = -1;   // PT_KERNEL_AUTO: 0 / 1 = this call is the timed trial of the persistent kernel / the pipeline
     if (kernel == PT_KERNEL_AUTO) {
         kernel = PT_KERNEL_PERSISTENT;
-        if (wave_ok && !c->opt_counters) {
+        if (wave_ok && !c->opt_counters && !(p->flags & PT_FLAG_NEE)) {
             pt_ctx::AutoPick& a = c->pick;
             uint64_t key = 0xcbf29ce484222325ull;
             const uint64_t parts[] = {(uint64_t)p->width, (uint64_t)p->height, (uint64_t)spp, (uint64_t)p->depth, (uint64_t)p->part_index,
@@ -502,6 +503,12 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
                 kernel = a.choice;
             }
         }
+    }
+    if (p->flags & PT_FLAG_NEE) {   // shadow rays: the stage-split pipeline has a stage for them, the megakernel a loop; the
+                                    // persistent kernel does not (its lanes have no room for a second ray)
+        const bool nee_wave = wave_ok && (uint64_t)p->width * (uint64_t)p->height <= (1ull << 24);   // pixel | nee_mask << 24
+        if (kernel != PT_KERNEL_MEGA_BVH2) kernel = nee_wave ? PT_KERNEL_WAVEFRONT : PT_KERNEL_MEGA_BVH2;
+        if (kernel == PT_KERNEL_WAVEFRONT && !nee_wave) kernel = PT_KERNEL_MEGA_BVH2;
     }
     if (kernel == PT_KERNEL_WAVEFRONT && !wave_ok) kernel = PT_KERNEL_PERSISTENT;
     if (kernel == PT_KERNEL_MEGA_BVH2 && walk == 3) kernel = PT_KERNEL_PERSISTENT;   // Woop records: persistent kernel only

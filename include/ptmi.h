@@ -79,6 +79,13 @@ enum {
                                         with probability 0.9 p, p = max(col), and scale col by 0.9 / p — an expected
                                         0.81 per bounce: that renderer's energy loss, reproduced so that its images
                                         can be matched; PT_FLAG_RUSSIAN_ROULETTE is the unbiased one            */
+    PT_FLAG_NEE = 1u << 8,             /* next-event estimation at DIFF hits (needs PT_FLAG_COSINE_DIFF): one shadow ray towards
+                                        ONE of the emissive spheres the hit point is outside of (of the first 8 spheres;
+                                        picked uniformly, cone-sampled, weighted by their number), and a DIFF-sampled ray
+                                        that then lands on such a sphere does not count its emission again.  Spheres the
+                                        path is inside of (the reference room's glowing walls) and emissive triangles are
+                                        gathered by the bounce as before.  Same expectation, less noise for small lights;
+                                        runs in the stage-split pipeline (a shadow-ray stage per bounce) or the megakernel */
     PT_FLAG_MISS_KEEPS_PATH = 1u << 6  /* a segment that hits nothing ends the path with
                                         accu + mask * bk_color (smallpt, and the reference's own CPU
                                         tracer: CpuRayTracer/src/scene.cpp:27 returns black for the

@@ -395,6 +395,7 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
     orc_camera_ray(cam, px, py, P->width, P->height, u0, u1, o_, d_);
     v3 o = V(o_[0], o_[1], o_[2]), d = V(d_[0], d_[1], d_[2]);
     v3 mask = V(1, 1, 1), accu = V(0, 0, 0);
+    uint32_t nee_mask = 0; /* PT_FLAG_NEE: spheres whose light the previous bounce already sampled */
     v3 tricol = V(P->tri_col[0], P->tri_col[1], P->tri_col[2]);
     v3 triemi = V(P->tri_emi[0], P->tri_emi[1], P->tri_emi[2]);
 
@@ -439,7 +440,9 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             if (P->flags & PT_FLAG_MISS_KEEPS_PATH) return vadd(accu, vmul(mask, bk)); /* extension (ptmi.h) */
             return bk; /* tracer.cu:140-142 */
         }
-        accu = vadd(accu, vmul(mask, emit));
+        if (!(geom == 1 && sph_id < 8 && ((nee_mask >> sph_id) & 1u))) /* not already gathered by a shadow ray */
+            accu = vadd(accu, vmul(mask, emit));
+        nee_mask = 0;
 
         if ((P->flags & PT_FLAG_RUSSIAN_ROULETTE) && depth >= 2) { /* extension (ptmi.h) */
             float pr = fmaxf(objcol.x, fmaxf(objcol.y, objcol.z));
@@ -475,6 +478,56 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             nextdir = vnormalize(nextdir);
             hitpos = vmadd(nl, 0.001f, hitpos);
             mask = vmul(mask, objcol);
+            if ((P->flags & PT_FLAG_NEE) && (P->flags & PT_FLAG_COSINE_DIFF)) { /* extension (ptmi.h) */
+                /* lights = emissive spheres (of the first 8) the point is outside of */
+                uint32_t el = 0;
+                int n_el = 0;
+                for (size_t i = 0; i < n_sph && i < 8; i++) {
+                    const pt_sphere* s = &sph[i];
+                    if (s->emi[0] == 0.0f && s->emi[1] == 0.0f && s->emi[2] == 0.0f) continue;
+                    v3 w = vsub(V(s->pos_rad[0], s->pos_rad[1], s->pos_rad[2]), hitpos);
+                    if (vdot(w, w) > (s->pos_rad[3] * s->pos_rad[3]) * 1.001f) { el |= 1u << i; n_el++; }
+                }
+                nee_mask = el;
+                if (n_el > 0) {
+                    float u0 = rng_next(rng), u1 = rng_next(rng), u2 = rng_next(rng);
+                    int pick = (int)(u0 * (float)n_el);
+                    if (pick > n_el - 1) pick = n_el - 1;
+                    int li = 0;
+                    for (int i = 0, k = 0; i < 8; i++)
+                        if ((el >> i) & 1u) { if (k == pick) { li = i; break; } k++; }
+                    const pt_sphere* L = &sph[li];
+                    v3 w = vsub(V(L->pos_rad[0], L->pos_rad[1], L->pos_rad[2]), hitpos);
+                    float d2 = vdot(w, w), r2 = L->pos_rad[3] * L->pos_rad[3];
+                    v3 wn = vscale(w, 1.0f / sqrtf(d2));
+                    float cos_max = sqrtf(fmaxf(0.0f, 1.0f - r2 / d2));
+                    float cos_t = 1.0f - u1 * (1.0f - cos_max);
+                    float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+                    float cp, sp;
+                    orc_sincos2pi(u2, &cp, &sp);
+                    v3 t1 = fabsf(wn.x) > fabsf(wn.y) ? V(wn.z, 0, -wn.x) : V(0, -wn.z, wn.y);
+                    t1 = vnormalize(t1);
+                    v3 b1 = vnormalize(vcross(wn, t1));
+                    v3 l = vnormalize(vmadd(t1, sp * sin_t, vmadd(wn, cos_t, vscale(b1, cp * sin_t))));
+                    float cosl = vdot(nl, l);
+                    float t_light = sphere_intersect(L, hitpos, l);
+                    int blocked = !(cosl > 0.0f) || t_light == 0.0f;
+                    for (size_t j = 0; j < n_sph && !blocked; j++) {
+                        if ((int)j == li) continue;
+                        float ts = sphere_intersect(&sph[j], hitpos, l);
+                        if (ts != 0.0f && ts < t_light && ts > 0.01f) blocked = 1;
+                    }
+                    if (!blocked) {
+                        hit_t h2 = {F32_MAX, -1, {0, 0, 0}};
+                        if (nodes) h2 = bvh_intersect(nodes, tris, tidx, hitpos, l, P->cull_backfaces, cnt);
+                        else if (cnt) cnt->rays++;
+                        if (!(h2.t < t_light)) {
+                            float k = (cosl * (2.0f * (1.0f - cos_max))) * (float)n_el;
+                            accu = vadd(accu, vscale(vmul(mask, V(L->emi[0], L->emi[1], L->emi[2])), k));
+                        }
+                    }
+                }
+            }
         } else if (mat == PT_MAT_SPEC) { /* :190-203 */
             nextdir = vnormalize(vmadd(nl, -2.0f * vdot(nl, d), d));
             hitpos = vmadd(nl, 0.001f, hitpos);
