@@ -7,7 +7,10 @@
 // (path_begin / trav_run_wide / path_shade_hit are the functions the other frame kernels call), so the
 // images are the same bit for bit — only WHERE a path's state lives between segments differs:
 //
-//   generate   one lane per (sample, pixel) slot in tile order: camera ray -> ray record, sample colour = 0
+//   bounce 0   works on SLOTS, one per (sample, pixel) in the tile order of the other frame kernels: both stages
+//              compute the camera ray from the slot number (a few dozen instructions) instead of a generate
+//              kernel writing 32-byte ray records for them to read back; the shade stage of bounce 0 WRITES
+//              the sample colour (accu = 0 + emission) instead of adding to a zeroed one
 //   per bounce
 //     extend   persistent waves: a wave draws REGIONS of the ray queue from eight sharded counters,
 //              walks the BVH for 64 rays at a time and refills a lane as soon as its ray is done (its whole
@@ -65,43 +68,25 @@ __global__ void __launch_bounds__(256) k_wf_prepare(const KParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// generate: slot = region * 256 + thread, in the tile order of the other frame kernels (slot >> 6 = work
-// tile = (sample, tile), slot & 63 = pixel of the 8x8 tile), so a wave's primary rays are coherent.
-__global__ void __launch_bounds__(PT_BLOCK) k_wf_generate(const KParams P) {
-    __shared__ int s_cnt[PT_BLOCK / 64];
-    const uint32_t slot = blockIdx.x * PT_REGION + threadIdx.x;
+// slot = region * 256 + thread, in the tile order of the other frame kernels (slot >> 6 = work tile =
+// (sample, tile), slot & 63 = pixel of the 8x8 tile), so a wave's primary rays are coherent.  False for the
+// slots of a partial tile that lie outside the image (tracer.cu:358).
+__device__ __forceinline__ bool wf_slot_pixel(const KParams& P, uint32_t slot, uint32_t& s_idx, int& px, int& py) {
+    if (slot >= P.wf.n_slots) return false;
     int wt = (int)(slot >> 6);
-    const uint32_t s_idx = (uint32_t)(wt / P.n_tiles);
+    s_idx = (uint32_t)(wt / P.n_tiles);
     wt -= (int)s_idx * P.n_tiles;
-    bool valid = s_idx < P.spp;
-    int tx = 0, ty = 0, px = 0, py = 0;
-    if (valid) valid = pt_tile_coords(P, wt, tx, ty);
-    if (valid) {
-        px = tx * PT_TILE + (int)(slot & 7u);
-        py = ty * PT_TILE + (int)((slot >> 3) & 7u);
-        valid = px < P.W && py < P.H;  // tracer.cu:358
-    }
-    PathState ps;
-    uint32_t pix = 0;
-    if (valid) {
-        pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
-        path_begin(P, px, py, (uint64_t)pix, P.frame + s_idx, ps);
-    }
-    int total;
-    const int r = wf_block_rank(valid, total, s_cnt);
-    if (valid) {
-        const size_t i = (size_t)blockIdx.x * PT_REGION + (size_t)r;
-        P.wf.ray0_out[i] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-        P.wf.ray1_out[i] = make_float4(ps.d.y, ps.d.z, __uint_as_float(pix), __uint_as_float((s_idx << 12) | ps.rng.n));
-        float* dst = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
-        dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;   // accu = 0 (tracer.cu:48)
-    }
-    if (threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = total;
+    int tx = 0, ty = 0;
+    if (s_idx >= P.spp || !pt_tile_coords(P, wt, tx, ty)) return false;
+    px = tx * PT_TILE + (int)(slot & 7u);
+    py = ty * PT_TILE + (int)((slot >> 3) & 7u);
+    return px < P.W && py < P.H;
 }
 
 // ------------------------------------------------------------------------------------------------
 // extend: the closest-hit walk (rows a5-a7) over the ray queue; see the file header.
-template <bool COUNT, int OCC, int LSTK>
+// FIRST: bounce 0 — a region is 256 consecutive slots and the ray is the slot's camera ray.
+template <bool COUNT, int OCC, int LSTK, bool FIRST>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,9 +133,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                         const uint32_t r = k * PT_SHARDS + (uint32_t)shard;
                         if (k < shard_regions && r < n_regions) {
-                            const int c = __builtin_amdgcn_readfirstlane(P.wf.cnt_in[r]);
                             next = r * PT_REGION;
-                            end = next + (uint32_t)c;
+                            if (FIRST) end = min(next + (uint32_t)PT_REGION, P.wf.n_slots);
+                            else end = next + (uint32_t)__builtin_amdgcn_readfirstlane(P.wf.cnt_in[r]);
                             got = true;
                         } else {
                             shard = (shard + 1) & (PT_SHARDS - 1);
@@ -161,11 +146,23 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                 const uint32_t take = min((uint32_t)n_idle - served, end - next);
                 if (!live && rank >= served && rank < served + take) {
                     idx = next + (rank - served);
-                    const float4 a = P.wf.ray0_in[idx], b = P.wf.ray1_in[idx];
-                    o = V3(a.x, a.y, a.z);
-                    d = V3(a.w, b.x, b.y);
-                    trav_begin(ts, o, d, stk, P.sc.wide_root);
-                    live = true;
+                    if (FIRST) {
+                        uint32_t s_idx = 0;
+                        int px = 0, py = 0;
+                        if (wf_slot_pixel(P, idx, s_idx, px, py)) {
+                            PathState ps;
+                            path_begin_hashed(P, px, py, (uint64_t)((uint32_t)py * (uint32_t)P.W + (uint32_t)px), P.wf.hashes[s_idx], ps);
+                            o = ps.o;
+                            d = ps.d;
+                            live = true;
+                        }
+                    } else {
+                        const float4 a = P.wf.ray0_in[idx], b = P.wf.ray1_in[idx];
+                        o = V3(a.x, a.y, a.z);
+                        d = V3(a.w, b.x, b.y);
+                        live = true;
+                    }
+                    if (live) trav_begin(ts, o, d, stk, P.sc.wide_root);
                 }
                 next += take;
                 served += take;
@@ -213,41 +210,48 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
 
 // ------------------------------------------------------------------------------------------------
 // shade: one bounce of tracer.cu:98-296 for every live record of a region; see the file header.
-template <bool COUNT>
+// FIRST: bounce 0 — lane = slot; the path starts here (camera ray, RNG) and the sample colour is written, not added to.
+template <bool COUNT, bool NEE, bool FIRST>
 __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
     __shared__ int s_cnt2[PT_BLOCK / 64];
     wf_sphere_table();
-    const int n_in = P.wf.cnt_in[blockIdx.x];
+    const int n_in = FIRST ? PT_REGION : P.wf.cnt_in[blockIdx.x];
     const bool last = P.wf.bounce + 1 >= P.depth;
     if (n_in == 0) {
         if (!last && threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = 0;
-        if (P.wf.nee && threadIdx.x == 0) P.wf.s_cnt[blockIdx.x] = 0;
+        if (NEE && threadIdx.x == 0) P.wf.s_cnt[blockIdx.x] = 0;
         return;
     }
-    const bool have = (int)threadIdx.x < n_in;
     const size_t i = (size_t)blockIdx.x * PT_REGION + threadIdx.x;
+    bool have = (int)threadIdx.x < n_in;
     bool alive = false, tri_hit = false;
     PathState ps;
     NeeReq req;
     req.want = false;
     uint32_t pix = 0, s_idx = 0;
+    int px = 0, py = 0;
+    if (FIRST) have = wf_slot_pixel(P, (uint32_t)i, s_idx, px, py);
     if (have) {
-        const float4 a = P.wf.ray0_in[i], b = P.wf.ray1_in[i];
+        if (FIRST) {
+            pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
+            path_begin_hashed(P, px, py, (uint64_t)pix, P.wf.hashes[s_idx], ps);
+        } else {
+            const float4 a = P.wf.ray0_in[i], b = P.wf.ray1_in[i];
+            ps.o = V3(a.x, a.y, a.z);
+            ps.d = V3(a.w, b.x, b.y);
+            pix = __float_as_uint(b.z);
+            ps.nee_mask = 0;
+            if (NEE) { ps.nee_mask = pix >> 24; pix &= 0xffffffu; }
+            const uint32_t sn = __float_as_uint(b.w);
+            s_idx = sn >> 12;
+            ps.mask = V3(P.wf.mask_in[i], P.wf.mask_in[(size_t)P.wf.cap + i], P.wf.mask_in[2 * (size_t)P.wf.cap + i]);
+            ps.accu = V3(0.f, 0.f, 0.f);   // this segment's emission only: the running sum lives in the sample buffer
+            ps.depth = P.wf.bounce;
+            ps.rng = pt_rng_init(P.wf.hashes[s_idx], (uint64_t)pix);
+            ps.rng.n = sn & 0xfffu;
+        }
         const float2 hh = P.wf.hit[i];
-        ps.o = V3(a.x, a.y, a.z);
-        ps.d = V3(a.w, b.x, b.y);
-        pix = __float_as_uint(b.z);
-        ps.nee_mask = 0;
-        if (P.wf.nee) { ps.nee_mask = pix >> 24; pix &= 0xffffffu; }
-        const uint32_t sn = __float_as_uint(b.w);
-        s_idx = sn >> 12;
-        ps.mask = V3(1.f, 1.f, 1.f);
-        if (P.wf.bounce > 0) ps.mask = V3(P.wf.mask_in[i], P.wf.mask_in[(size_t)P.wf.cap + i], P.wf.mask_in[2 * (size_t)P.wf.cap + i]);
-        ps.accu = V3(0.f, 0.f, 0.f);   // this segment's emission only: the running sum lives in the sample buffer
-        ps.depth = P.wf.bounce;
-        ps.rng = pt_rng_init(P.wf.hashes[s_idx], (uint64_t)pix);
-        ps.rng.n = sn & 0xfffu;
         Hit h;
         h.t = hh.x;
         h.rec = __float_as_int(hh.y);
@@ -264,16 +268,20 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
         const SceneHit sh = pt_closest_sphere(P, ps.o, ps.d, h, 0);
         if (sh.geom == 3) {   // tracer.cu:140-142: the sample IS the background colour, whatever was gathered before
             PT_KARGS(K);
-            if (K.flags & PT_FLAG_MISS_KEEPS_PATH) {   // extension: accu (= the sample buffer) + mask * bk
+            if (FIRST && (K.flags & PT_FLAG_MISS_KEEPS_PATH)) {
+                smp[0] = 0.f + ps.mask.x * K.bk[0]; smp[1] = 0.f + ps.mask.y * K.bk[1]; smp[2] = 0.f + ps.mask.z * K.bk[2];
+            } else if (K.flags & PT_FLAG_MISS_KEEPS_PATH) {   // extension: accu (= the sample buffer) + mask * bk
                 smp[0] += ps.mask.x * K.bk[0]; smp[1] += ps.mask.y * K.bk[1]; smp[2] += ps.mask.z * K.bk[2];
             } else {
                 smp[0] = K.bk[0]; smp[1] = K.bk[1]; smp[2] = K.bk[2];
             }
         } else {
             v3 col;
-            const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0, P.wf.nee ? &req : nullptr);
+            const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0, NEE ? &req : nullptr);
             const v3 e = done ? col : ps.accu;   // mask * emission of this hit (accu entered as 0)
-            if (!(e.x == 0.f) || !(e.y == 0.f) || !(e.z == 0.f)) {
+            if (FIRST) {   // accu = 0 (tracer.cu:48) + this hit's emission
+                smp[0] = 0.f + e.x; smp[1] = 0.f + e.y; smp[2] = 0.f + e.z;
+            } else if (!(e.x == 0.f) || !(e.y == 0.f) || !(e.z == 0.f)) {
                 smp[0] += e.x; smp[1] += e.y; smp[2] += e.z;
             }
             alive = !done;
@@ -286,7 +294,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             atomicAdd(&P.counters[5], (unsigned long long)np);
         }
     }
-    if (P.wf.nee) {   // PT_FLAG_NEE: the shadow rays of this bounce's DIFF hits, packed like the survivors
+    if (NEE) {   // PT_FLAG_NEE: the shadow rays of this bounce's DIFF hits, packed like the survivors
         int n_sh;
         const int rs = wf_block_rank(req.want, n_sh, s_cnt2);
         if (req.want) {
@@ -303,7 +311,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     if (alive) {
         const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)r;
         P.wf.ray0_out[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(P.wf.nee ? (pix | (ps.nee_mask << 24)) : pix),
+        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(NEE ? (pix | (ps.nee_mask << 24)) : pix),
                                        __uint_as_float((s_idx << 12) | ps.rng.n));
         P.wf.mask_out[j] = ps.mask.x;
         P.wf.mask_out[(size_t)P.wf.cap + j] = ps.mask.y;
@@ -384,10 +392,9 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     P.wf.queues_words = (uint32_t)q_words;
     P.wf.cap = (uint32_t)cap;
     P.wf.n_regions = (int)n_regions;
+    P.wf.n_slots = (uint32_t)((size_t)work_tiles * 64);
     P.wf.bounce = 0;
     hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(256), 0, st, P);
-    P.wf.ray0_out = ray0[0]; P.wf.ray1_out = ray1[0]; P.wf.mask_out = mask[0]; P.wf.cnt_out = cnt[0];
-    hipLaunchKernelGGL(k_wf_generate, dim3((unsigned)n_regions), dim3(PT_BLOCK), 0, st, P);
     HIP_TRY(c, hipGetLastError());
     if (stage_mark(c, PT_STAGE_GENERATE) != PT_OK) return PT_ERR_DEVICE;
 
@@ -399,21 +406,31 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
         P.wf.ray0_in = ray0[g]; P.wf.ray1_in = ray1[g]; P.wf.mask_in = mask[g]; P.wf.cnt_in = cnt[g];
         P.wf.ray0_out = ray0[g ^ 1]; P.wf.ray1_out = ray1[g ^ 1]; P.wf.mask_out = mask[g ^ 1]; P.wf.cnt_out = cnt[g ^ 1];
         P.wf.queue = queues + (size_t)b * PT_SHARDS * PT_SHARD_STRIDE;
-#define PT_EXT(COUNT, OCC, LSTK)                                                                                  \
+#define PT_EXT(COUNT, OCC, LSTK, FIRST)                                                                           \
         do {                                                                                                      \
             int per_cu = 0;                                                                                       \
-            HIP_TRY(c, allow_lds(k_wf_extend<COUNT, OCC, LSTK>, lds_ext));                                        \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
+            HIP_TRY(c, allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST>, lds_ext));                                 \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK, FIRST>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
                 per_cu = 1;                                                                                       \
             per_cu = std::min(per_cu, c->opt_wave_blocks);                                                        \
-            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, n_regions)), \
+            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, n_regions)), \
                                dim3(PT_BLOCK), lds_ext, st, P);                                                   \
         } while (0)
-        if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24); else PT_EXT(true, 8, 16); }
-        else { if (L.lstk == 24) PT_EXT(false, 6, 24); else PT_EXT(false, 8, 16); }
+#define PT_EXT_ANY(FIRST)                                                                                         \
+        do {                                                                                                      \
+            if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24, FIRST); else PT_EXT(true, 8, 16, FIRST); }       \
+            else { if (L.lstk == 24) PT_EXT(false, 6, 24, FIRST); else PT_EXT(false, 8, 16, FIRST); }             \
+        } while (0)
+#define PT_SHADE(COUNT, NEE, FIRST) \
+        hipLaunchKernelGGL((k_wf_shade<COUNT, NEE, FIRST>), dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P)
+#define PT_SHADE_ANY(FIRST)                                                                                       \
+        do {                                                                                                      \
+            if (nee) { if (L.count) PT_SHADE(true, true, FIRST); else PT_SHADE(false, true, FIRST); }             \
+            else { if (L.count) PT_SHADE(true, false, FIRST); else PT_SHADE(false, false, FIRST); }               \
+        } while (0)
+        if (b == 0) PT_EXT_ANY(true); else PT_EXT_ANY(false);
         if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
-        if (L.count) hipLaunchKernelGGL(k_wf_shade<true>, dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P);
-        else hipLaunchKernelGGL(k_wf_shade<false>, dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P);
+        if (b == 0) PT_SHADE_ANY(true); else PT_SHADE_ANY(false);
         HIP_TRY(c, hipGetLastError());
         if (stage_mark(c, PT_STAGE_SHADE) != PT_OK) return PT_ERR_DEVICE;
         if (nee) {   // this bounce's shadow rays: the same extend kernel over the shadow records, then the resolve
@@ -422,8 +439,7 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
             S.wf.queue = queues + ((size_t)P.depth + b) * PT_SHARDS * PT_SHARD_STRIDE;
             const KParams keep = P;
             P = S;
-            if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24); else PT_EXT(true, 8, 16); }
-            else { if (L.lstk == 24) PT_EXT(false, 6, 24); else PT_EXT(false, 8, 16); }
+            PT_EXT_ANY(false);
             P = keep;
             if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
             hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)n_regions), dim3(PT_BLOCK), 0, st, P);
@@ -432,6 +448,9 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
         }
     }
 #undef PT_EXT
+#undef PT_EXT_ANY
+#undef PT_SHADE
+#undef PT_SHADE_ANY
     return PT_OK;
 }
 

@@ -31,9 +31,10 @@ struct NeeReq {
     const __attribute__((address_space(4))) KParams& K = *K##_p
 
 // RNG seed (tracer.cu:362-363) + getCamRayDir, cudaUtils.h:111-134 (origin ON the image plane)
-__device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uint64_t pix, uint64_t frame, PathState& ps) {
+// (frame_hash = pt_wang64(frame), uf::hash of utilfun.cpp:380-389)
+__device__ __forceinline__ void path_begin_hashed(const KParams& P, int px, int py, uint64_t pix, uint64_t frame_hash, PathState& ps) {
     PT_KARGS(K);   // camera: read where it is used, not held in SGPRs across the persistent loop
-    ps.rng = pt_rng_init(pt_wang64(frame), pix);
+    ps.rng = pt_rng_init(frame_hash, pix);
     const float u0 = pt_rng_next(ps.rng), u1 = pt_rng_next(ps.rng);
     const float jx = u0 - 0.5f, jy = u1 - 0.5f;
     const float xs = ((((float)px - (float)P.W / 2.0f) + 0.5f) + jx) * K.cam.dist * K.cam.aspect * K.cam.fov / (float)(P.W - 1);
@@ -48,6 +49,9 @@ __device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uin
     ps.accu = V3(0.f, 0.f, 0.f);
     ps.depth = 0;
     ps.nee_mask = 0;
+}
+__device__ __forceinline__ void path_begin(const KParams& P, int px, int py, uint64_t pix, uint64_t frame, PathState& ps) {
+    path_begin_hashed(P, px, py, pix, pt_wang64(frame), ps);
 }
 
 // What a segment ended on once the spheres have been tested too (intersectAllSpeheres,

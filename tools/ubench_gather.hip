@@ -7,6 +7,8 @@
 //           lane's item per instruction (4 instructions serve the quad's 4 items), data is
 //           handed to the owner with DPP quad_perm moves
 //   mode 2: as mode 0 but 2 x dwordx4 (32-byte items: a compressed node)
+//   mode 7: quad per item: the 4 lanes of a quad chase ONE chain, each lane loads one 16-byte piece of the
+//           item (one instruction per item, 16 lines per wave instruction); items/s counts quads
 // Dependent chain: the next index depends on the loaded data, like pointer chasing.
 // Build: hipcc --offload-arch=gfx950 -O3 -o ubench_gather tools/ubench_gather.hip
 #include <hip/hip_runtime.h>
@@ -30,7 +32,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ items, uint32_t n_items, int iters, float* out) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int ql = threadIdx.x & 3;
-    uint32_t idx = mix(gid * 2654435761u + 12345u) % n_items;
+    uint32_t idx = mix((MODE == 7 ? gid >> 2 : gid) * 2654435761u + 12345u) % n_items;
     float acc = 0.f;
     for (int it = 0; it < iters; it++) {
         float4 q0, q1, q2, q3;
@@ -50,6 +52,13 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ it
         } else if (MODE == 5) {  // 48 bytes: 3 x dwordx4
             const float4* p = items + (size_t)idx * 4;
             q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = q2;
+        } else if (MODE == 7) {  // one item per QUAD: lane ql loads piece ql; the quad shares the sum
+            const float4 r = items[(size_t)idx * 4 + ql];
+            float t = r.x + r.y + r.z + r.w;
+            t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+            t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+            q0 = make_float4(t, 0.f, 0.f, 0.f); q1 = q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            q3 = make_float4(0.f, 0.f, 0.f, quad_bcast<3>(r.w));
         } else if (MODE == 6) {  // 128 bytes: 8 x dwordx4 (two consecutive items)
             const float4* p = items + (size_t)(idx & ~1u) * 4;
             const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g2 = p[6], h = p[7];
@@ -127,7 +136,7 @@ int main(int argc, char** argv) {
     hipMalloc(&d_out, (size_t)blocks * threads * 4);
     hipMemcpy(d_items, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 7; mode++) {
+    for (int mode = 0; mode < 8; mode++) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             hipEventRecord(e0);
@@ -137,13 +146,14 @@ int main(int argc, char** argv) {
             else if (mode == 3) hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 4) hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 5) hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
-            else hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 6) hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep > 0 && ms < best) best = ms;
         }
-        const double items_n = (double)blocks * threads * iters;
-        static const int bytes_of[7] = {64, 64, 32, 16, 32, 48, 128};
+        const double items_n = (double)blocks * threads * iters / (mode == 7 ? 4 : 1);
+        static const int bytes_of[8] = {64, 64, 32, 16, 32, 48, 128, 64};
         const double bytes = items_n * bytes_of[mode];
         printf("mode %d: %.3f ms  %.1f Gitems/s  %.1f GB/s chip  %.1f GB/s per CU\n", mode, best, items_n / best / 1e6,
                bytes / best / 1e6, bytes / best / 1e6 / 256);
