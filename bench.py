@@ -548,7 +548,7 @@ def main():
                                 "items_per_ray": round(b_items / bc["rays"], 2),
                                 "requested_gbs": round((b_items * 64.0 + b_stream) / (bst[bdom] * 1e-3) / 1e9, 1),
                                 "hbm_frac_of_peak_if_all_missed": round((b_items * 64.0 + b_stream) / (bst[bdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            trb = os.path.join(ROOT, "profiles", "r02d_big_scene_pmc_traffic.json")
+            trb = os.path.join(ROOT, "profiles", "r02_big_scene_pmc_traffic.json")
             if os.path.exists(trb) and bdom == "extend":
                 jb = json.load(open(trb))
                 wb = jb.get("kernels", {}).get("k_wf_extend")
@@ -557,7 +557,7 @@ def main():
                     out["big_scene"]["hbm_measured"] = {"bytes_per_extend_launch": wb["hbm_bytes_per_launch"],
                                                         "gbs": round(wb["hbm_bytes_per_launch"] / (per_launch_ms * 1e-3) / 1e9, 1),
                                                         "frac_of_hbm_peak": round(wb["hbm_bytes_per_launch"] / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                        "source": "profiles/r02d_big_scene_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE raw = TCC_MISS x 64 B for gathers, + WRITE_SIZE; same kernel sources)"}
+                                                        "source": "profiles/r02_big_scene_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE raw = TCC_MISS x 64 B for gathers, + WRITE_SIZE; same kernel sources)"}
             gb = gather_bound(binfo["device_bytes"])
             if gb and "items_per_s" in gb:
                 out["big_scene"]["gather_bound"] = {"gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),

@@ -375,6 +375,18 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
               asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(dummy) : "v"(ptr_) : "memory");
               asm volatile("" :: "v"(dummy.x), "v"(dummy.w)); }
 #endif
+#ifdef PT_EXP_SALU   // sensitivity experiment: 32 more dependent scalar instructions per node step
+            { int z = 1;
+#pragma unroll
+              for (int e = 0; e < 32; e++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(z) :: "scc");
+              asm volatile("" :: "s"(z)); }
+#endif
+#ifdef PT_EXP_BRANCH   // sensitivity experiment: 8 more (never taken) exec-mask branch pairs per node step
+            { int zb = w.l0;
+#pragma unroll
+              for (int e = 0; e < 8; e++) { if (zb == 0x7fffff01 + e) { asm volatile("v_mov_b32 %0, 0" : "+v"(zb)); } asm volatile("" : "+v"(zb)); }
+              asm volatile("" :: "v"(zb)); }
+#endif
 #ifdef PT_EXP_VALU   // sensitivity experiment: 32 more dependent VALU instructions per node step
             { float z = w.ox;
 #pragma unroll

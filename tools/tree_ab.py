@@ -22,6 +22,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--presplit", default="0,50,100,200")
+ap.add_argument("--leaf-max", default="")
 a = ap.parse_args()
 W, H = a.width, a.height
 
@@ -52,6 +53,8 @@ for scene in a.scenes.split(","):
     if scene == "dragon":
         cam.dist = 18.0
     rows = [("host tree (upload)", dict(upload=True)), ("upload + PT_OPT_REBUILD", dict(upload=True, rebuild=1))]
+    for lm in a.leaf_max.split(",") if a.leaf_max else ():
+        rows.append((f"host tree, PT_OPT_LEAF_MAX {lm}", dict(upload=True, leaf_max=int(lm))))
     for ps in a.presplit.split(","):
         rows.append((f"pt_build_bvh PLOC presplit {ps}", dict(algo=1, presplit=int(ps))))
     rows.append(("pt_build_bvh LBVH", dict(algo=0, presplit=0)))
@@ -64,6 +67,8 @@ for scene in a.scenes.split(","):
             pt.set_option(g.OPT_KERNEL, kernel)
             if o.get("upload"):
                 pt.set_option(g.OPT_REBUILD, o.get("rebuild", 0))
+                if "leaf_max" in o:
+                    pt.set_option(g.OPT_LEAF_MAX, o["leaf_max"])
                 pt.upload_bvh(bvh)
                 b_ms = -1.0
             else:
