@@ -24,6 +24,12 @@ struct pt_ctx {
     int* d_tri_matid = nullptr;        // pt_upload_tri_materials
     float4* d_mat_table = nullptr;
     size_t n_tri_matid = 0;
+    // PT_FLAG_NEE over emissive triangles: ids whose material row emits (host, ascending), id -> light slot (device),
+    // the light records (device; rebuilt from the triangle records when the scene or the materials changed)
+    std::vector<int32_t> emissive_ids;
+    int32_t* d_light_slot = nullptr;
+    float4* d_tri_lights = nullptr;
+    uint64_t mat_gen = 0, lights_key = ~0ull;
     int32_t max_tri_id = -1;           // largest original triangle id of the uploaded BVH
     int n_spheres = 0;
     pt_sphere_d h_spheres[PT_KSPHERES];   // host copy of the first spheres for the kernel-argument block

@@ -242,8 +242,12 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             ps.d = V3(a.w, b.x, b.y);
             pix = __float_as_uint(b.z);
             ps.nee_mask = 0;
-            if (NEE) { ps.nee_mask = pix >> 24; pix &= 0xffffffu; }
-            const uint32_t sn = __float_as_uint(b.w);
+            uint32_t sn = __float_as_uint(b.w);
+            if (NEE) {   // the sphere bits ride above the pixel, the triangle-light bit above the sample number
+                ps.nee_mask = (pix >> 24) | ((sn >> 31) << 8);
+                pix &= 0xffffffu;
+                sn &= 0x7fffffffu;
+            }
             s_idx = sn >> 12;
             ps.mask = V3(P.wf.mask_in[i], P.wf.mask_in[(size_t)P.wf.cap + i], P.wf.mask_in[2 * (size_t)P.wf.cap + i]);
             ps.accu = V3(0.f, 0.f, 0.f);   // this segment's emission only: the running sum lives in the sample buffer
@@ -311,8 +315,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     if (alive) {
         const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)r;
         P.wf.ray0_out[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(NEE ? (pix | (ps.nee_mask << 24)) : pix),
-                                       __uint_as_float((s_idx << 12) | ps.rng.n));
+        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(NEE ? (pix | ((ps.nee_mask & 0xffu) << 24)) : pix),
+                                       __uint_as_float((s_idx << 12) | ps.rng.n | (NEE ? (ps.nee_mask >> 8) << 31 : 0u)));
         P.wf.mask_out[j] = ps.mask.x;
         P.wf.mask_out[(size_t)P.wf.cap + j] = ps.mask.y;
         P.wf.mask_out[2 * (size_t)P.wf.cap + j] = ps.mask.z;
@@ -348,6 +352,7 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     const size_t b_ray = cap * 16, b_mask = cap * 12, b_hit = cap * 8, b_cnt = ((n_regions * 4 + 255) / 256) * 256;
     const size_t b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
     const bool nee = (P.flags & PT_FLAG_NEE) != 0;
+    if (nee && P.spp >= (1u << 19)) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_FLAG_NEE in the stage-split pipeline packs < 2^19 samples per call into a path record");
     const size_t q_words = (size_t)P.depth * (nee ? 2 : 1) * PT_SHARDS * PT_SHARD_STRIDE, b_q = q_words * 4;
     const size_t b_nee = nee ? 3 * b_ray + b_hit + b_cnt : 0;   // shadow records: s_ray0, s_ray1, s_con, s_hit, s_cnt
     const size_t need = 4 * b_ray + 2 * b_mask + b_hit + 2 * b_cnt + b_hash + b_q + b_nee;

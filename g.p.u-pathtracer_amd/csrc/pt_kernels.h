@@ -89,6 +89,10 @@ struct KParams {
     // per-triangle materials (pt_upload_tri_materials): NULL = the reference's one global material
     const int* tri_matid;          // [original triangle id] -> row of mat_table
     const float4* mat_table;       // 2 float4 per material: (col, emi.x) (emi.yz, mat bits, phong)
+    // PT_FLAG_NEE: the triangles whose material row emits, ascending original id; 3 float4 each:
+    // (v0, emi.r) (e1 = v1 - v0, emi.g) (e2 = v2 - v0, emi.b) — copied from the triangle's record
+    const float4* tri_lights;
+    int n_tri_lights;
     uint32_t flags;
     // tile enumeration: tiles_x tiles per tile-row; this launch covers n_tiles tiles taken
     // from the tile-rows this partition owns (stripes of stripe_tr tile-rows, round-robin)

@@ -168,7 +168,8 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
         if (K.flags & PT_FLAG_MISS_KEEPS_PATH) col_out = vadd(accu, vmul(mask, col_out));  // extension
         return true;
     }
-    if (!(geom == 1 && sph_id < 8 && ((ps.nee_mask >> sph_id) & 1u)))   // not already gathered by a shadow ray (PT_FLAG_NEE)
+    // not already gathered by a shadow ray (PT_FLAG_NEE): bits 0-7 the spheres that were eligible, bit 8 the emissive triangles
+    if (!(geom == 1 && sph_id < 8 && ((ps.nee_mask >> sph_id) & 1u)) && !(geom == 0 && (ps.nee_mask & 0x100u)))
         accu = vadd(accu, vmul(mask, emit));
     ps.nee_mask = 0;
 
@@ -220,11 +221,44 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
                     if (lit && vdot(w, w) > (kp[11 * i + 3] * kp[11 * i + 3]) * 1.001f) { el |= 1u << i; n_el++; }
                 }
             }
-            ps.nee_mask = el;
-            if (n_el > 0) {
+            const int n_tl = K.n_tri_lights, n_all = n_el + n_tl;
+            ps.nee_mask = el | (n_tl > 0 ? 0x100u : 0u);
+            if (n_all > 0) {
                 const float u0 = pt_rng_next(rng), u1 = pt_rng_next(rng), u2 = pt_rng_next(rng);
-                int pick = (int)(u0 * (float)n_el);
-                if (pick > n_el - 1) pick = n_el - 1;
+                int pick = (int)(u0 * (float)n_all);
+                if (pick > n_all - 1) pick = n_all - 1;
+                if (pick >= n_el) {
+                    // an emissive triangle: a point uniform on it; the faces a path can hit emit (see `blocked`).  contribution = mask * Le * cos(surface) * cos(light) * area / (pi * dist^2) * lights
+                    const float4* tl = P.tri_lights + 3 * (size_t)(pick - n_el);
+                    const float4 t0 = tl[0], t1 = tl[1], t2 = tl[2];
+                    const v3 e1 = V3(t1.x, t1.y, t1.z), e2 = V3(t2.x, t2.y, t2.z);
+                    const float su = sqrtf(u1);
+                    const v3 pl = vmadd(e2, u2 * su, vmadd(e1, 1.0f - su, V3(t0.x, t0.y, t0.z)));
+                    const v3 w = vsub(pl, hitpos);
+                    const float d2 = vdot(w, w);
+                    const float dist = sqrtf(d2);
+                    const v3 l = vscale(w, 1.0f / dist);
+                    const float cosl = vdot(nl, l);
+                    const float sdot = vdot(vcross(e1, e2), l);
+                    const float proj = fabsf(sdot);   // 2 * area * cos(light)
+                    const float t_light = dist * 0.999f;
+                    // with back-face culling a path only ever HITS the front of a triangle (det > 0 <=> cross(e1, e2) . d < 0,
+                    // cudaUtils.h:150-160), so only that face is a light
+                    bool blocked = !(cosl > 0.0f) || !(d2 > 0.0f) || !(proj > 0.0f) || (P.cull != 0 && !(sdot < 0.0f));
+                    for (int j = 0; j < P.sc.n_spheres; j++) {
+                        const pt_sphere_d& sj = P.sc.spheres[j];
+                        const float ts = pt_sphere_intersect(sj.px, sj.py, sj.pz, sj.rad, hitpos, l);
+                        if (ts != 0.0f && ts < t_light && ts > 0.01f) blocked = true;
+                    }
+                    if (!blocked) {
+                        const float k = ((cosl * (0.5f * proj)) * (float)n_all) / (3.14159274f * d2);
+                        nee->want = true;
+                        nee->o = hitpos;
+                        nee->d = l;
+                        nee->t_max = t_light;
+                        nee->contrib = vscale(vmul(mask, V3(t0.w, t1.w, t2.w)), k);
+                    }
+                } else {
                 int li = 0;
                 {
                     int k = 0;
@@ -257,12 +291,13 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
                     if (j != li && ts != 0.0f && ts < t_light && ts > 0.01f) blocked = true;
                 }
                 if (!blocked) {
-                    const float k = (cosl * (2.0f * (1.0f - cos_max))) * (float)n_el;
+                    const float k = (cosl * (2.0f * (1.0f - cos_max))) * (float)n_all;
                     nee->want = true;
                     nee->o = hitpos;
                     nee->d = l;
                     nee->t_max = t_light;
                     nee->contrib = vscale(vmul(mask, V3(L.emi[0], L.emi[1], L.emi[2])), k);
+                }
                 }
             }
         }

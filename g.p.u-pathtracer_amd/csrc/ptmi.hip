@@ -97,6 +97,8 @@ int pt_destroy(pt_ctx* c) {
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_tri_matid);
     (void)hipFree(c->d_mat_table);
+    (void)hipFree(c->d_light_slot);
+    (void)hipFree(c->d_tri_lights);
     (void)hipFree(c->d_counters);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_samples);
@@ -348,7 +350,11 @@ int pt_upload_tri_materials(pt_ctx* c, const pt_material* table, size_t n_materi
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_tri_matid); c->d_tri_matid = nullptr;
         (void)hipFree(c->d_mat_table); c->d_mat_table = nullptr;
+        (void)hipFree(c->d_light_slot); c->d_light_slot = nullptr;
+        (void)hipFree(c->d_tri_lights); c->d_tri_lights = nullptr;
+        c->emissive_ids.clear();
         c->n_tri_matid = 0;
+        c->mat_gen++;
         return PT_OK;
     }
     if (!table || !tri_material) return fail(c, PT_ERR_INVALID, "pt_upload_tri_materials: null array");
@@ -369,7 +375,45 @@ int pt_upload_tri_materials(pt_ctx* c, const pt_material* table, size_t n_materi
     HIP_TRY(c, hipMemcpy(c->d_tri_matid, tri_material, n_tris * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_mat_table, table, n_materials * sizeof(pt_material), hipMemcpyHostToDevice));
     c->n_tri_matid = n_tris;
+    // PT_FLAG_NEE: the triangles that emit, in id order, and where each one's light record goes
+    (void)hipFree(c->d_light_slot); c->d_light_slot = nullptr;
+    (void)hipFree(c->d_tri_lights); c->d_tri_lights = nullptr;
+    c->emissive_ids.clear();
+    c->mat_gen++;
+    std::vector<int32_t> slot(n_tris, -1);
+    for (size_t i = 0; i < n_tris; i++) {
+        const pt_material& m = table[tri_material[i]];
+        if (!(m.emi[0] == 0.0f && m.emi[1] == 0.0f && m.emi[2] == 0.0f)) {
+            slot[i] = (int32_t)c->emissive_ids.size();
+            c->emissive_ids.push_back((int32_t)i);
+        }
+    }
+    if (!c->emissive_ids.empty()) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_light_slot, n_tris * sizeof(int32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_tri_lights, c->emissive_ids.size() * 3 * sizeof(float4)));
+        HIP_TRY(c, hipMemcpy(c->d_light_slot, slot.data(), n_tris * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return PT_OK;
+}
+
+// PT_FLAG_NEE: copies (v0, e1, e2) of every emissive triangle from its record into its light slot (a triangle a spatial
+// split lists more than once is listed in full each time: the copies write the same values)
+__global__ void __launch_bounds__(256) k_collect_tri_lights(const float4* __restrict__ rec, uint32_t n_rec, const int32_t* __restrict__ slot,
+                                                            uint32_t n_ids, const int* __restrict__ tri_matid, const float4* __restrict__ mat_table,
+                                                            float4* __restrict__ lights) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_rec) return;
+    const float4 q0 = rec[4 * (size_t)i];
+    const int id = __float_as_int(q0.w);
+    if (id < 0 || (uint32_t)id >= n_ids) return;
+    const int s = slot[id];
+    if (s < 0) return;
+    const float4 q1 = rec[4 * (size_t)i + 1], q2 = rec[4 * (size_t)i + 2];
+    const int row = tri_matid[id];
+    const float4 m0 = mat_table[2 * row], m1 = mat_table[2 * row + 1];
+    lights[3 * (size_t)s + 0] = make_float4(q0.x, q0.y, q0.z, m0.w);
+    lights[3 * (size_t)s + 1] = make_float4(q1.x, q1.y, q1.z, m1.x);
+    lights[3 * (size_t)s + 2] = make_float4(q2.x, q2.y, q2.z, m1.y);
 }
 
 int pt_upload_spheres(pt_ctx* c, const pt_sphere* spheres, size_t n) {
@@ -441,6 +485,20 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     P.tri_matid = c->d_tri_matid;
     P.mat_table = c->d_mat_table;
     P.flags = p->flags;
+    if ((p->flags & PT_FLAG_NEE) && c->has_bvh && !c->emissive_ids.empty()) {
+        if (c->records_woop) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_FLAG_NEE over emissive triangles needs the exact (Moller-Trumbore) records");
+        const uint64_t key = (c->scene_gen << 32) ^ c->mat_gen;
+        if (c->lights_key != key) {   // the scene or the materials changed: copy the lights' vertices out of the records again
+            const uint32_t n_rec = (uint32_t)c->n_refs;
+            HIP_TRY(c, hipMemsetAsync(c->d_tri_lights, 0, c->emissive_ids.size() * 3 * sizeof(float4), c->stream));
+            hipLaunchKernelGGL(k_collect_tri_lights, dim3((n_rec + 255) / 256), dim3(256), 0, c->stream, c->d_nodes + 4 * (size_t)c->n_inner, n_rec,
+                               c->d_light_slot, (uint32_t)c->n_tri_matid, c->d_tri_matid, c->d_mat_table, c->d_tri_lights);
+            HIP_TRY(c, hipGetLastError());
+            c->lights_key = key;
+        }
+        P.tri_lights = c->d_tri_lights;
+        P.n_tri_lights = (int)c->emissive_ids.size();
+    }
     P.tiles_x = (p->width + PT_TILE - 1) / PT_TILE;
     P.tile_rows = (p->height + PT_TILE - 1) / PT_TILE;
     if (p->part_count > 1) {

@@ -82,10 +82,15 @@ enum {
     PT_FLAG_NEE = 1u << 8,             /* next-event estimation at DIFF hits (needs PT_FLAG_COSINE_DIFF): one shadow ray towards
                                         ONE of the emissive spheres the hit point is outside of (of the first 8 spheres;
                                         picked uniformly, cone-sampled, weighted by their number), and a DIFF-sampled ray
-                                        that then lands on such a sphere does not count its emission again.  Spheres the
-                                        path is inside of (the reference room's glowing walls) and emissive triangles are
-                                        gathered by the bounce as before.  Same expectation, less noise for small lights;
-                                        runs in the stage-split pipeline (a shadow-ray stage per bounce) or the megakernel */
+                                        that then lands on such a sphere does not count its emission again.  With a material
+                                        table on the context (pt_upload_tri_materials) the TRIANGLES whose row emits are
+                                        lights too: the pick is uniform over eligible spheres + emissive triangles, a point
+                                        is drawn uniformly on the triangle (the faces a path can hit emit: the front one
+                                        under cull_backfaces, both otherwise), and the next DIFF-sampled hit on any emissive triangle is not counted again.
+                                        Spheres the path is inside of (the reference room's glowing walls) and triangles
+                                        lit by the one global material of pt_params are gathered by the bounce as before.
+                                        Same expectation, less noise for small lights; runs in the stage-split pipeline
+                                        (a shadow-ray stage per bounce) or the megakernel                                   */
     PT_FLAG_MISS_KEEPS_PATH = 1u << 6  /* a segment that hits nothing ends the path with
                                         accu + mask * bk_color (smallpt, and the reference's own CPU
                                         tracer: CpuRayTracer/src/scene.cpp:27 returns black for the

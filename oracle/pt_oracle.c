@@ -386,6 +386,16 @@ void orc_camera_ray(const pt_camera* cam, int px, int py, int w, int h, float u0
 
 /* ---------------------------------------------------------------- one sample */
 /* getSample, tracer.cu:27-339 */
+/* PT_FLAG_NEE over emissive triangles (ptmi.h): the light list the product derives from the material table —
+ * every triangle whose row emits, ascending original id, as (v0, emi.r) (e1 = v1 - v0, emi.g) (e2 = v2 - v0, emi.b),
+ * binary32 subtraction as at upload.  The tests build it from the mesh and hand it over before a render. */
+static const float* g_tri_lights = 0;
+static size_t g_n_tri_lights = 0;
+void orc_set_tri_lights(const float* lights12, size_t n) {
+    g_tri_lights = n ? lights12 : 0;
+    g_n_tri_lights = lights12 ? n : 0;
+}
+
 static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
                      const pt_sphere* sph, size_t n_sph, const pt_camera* cam,
                      const pt_params* P, const pt_material* mtab, const int32_t* tri_mat,
@@ -440,7 +450,8 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
             if (P->flags & PT_FLAG_MISS_KEEPS_PATH) return vadd(accu, vmul(mask, bk)); /* extension (ptmi.h) */
             return bk; /* tracer.cu:140-142 */
         }
-        if (!(geom == 1 && sph_id < 8 && ((nee_mask >> sph_id) & 1u))) /* not already gathered by a shadow ray */
+        /* not already gathered by a shadow ray: bits 0-7 the spheres that were eligible, bit 8 the emissive triangles */
+        if (!(geom == 1 && sph_id < 8 && ((nee_mask >> sph_id) & 1u)) && !(geom == 0 && (nee_mask & 0x100u)))
             accu = vadd(accu, vmul(mask, emit));
         nee_mask = 0;
 
@@ -488,11 +499,41 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
                     v3 w = vsub(V(s->pos_rad[0], s->pos_rad[1], s->pos_rad[2]), hitpos);
                     if (vdot(w, w) > (s->pos_rad[3] * s->pos_rad[3]) * 1.001f) { el |= 1u << i; n_el++; }
                 }
-                nee_mask = el;
-                if (n_el > 0) {
+                const int n_tl = mtab ? (int)g_n_tri_lights : 0, n_all = n_el + n_tl;
+                nee_mask = el | (n_tl > 0 ? 0x100u : 0u);
+                if (n_all > 0) {
                     float u0 = rng_next(rng), u1 = rng_next(rng), u2 = rng_next(rng);
-                    int pick = (int)(u0 * (float)n_el);
-                    if (pick > n_el - 1) pick = n_el - 1;
+                    int pick = (int)(u0 * (float)n_all);
+                    if (pick > n_all - 1) pick = n_all - 1;
+                    if (pick >= n_el) { /* an emissive triangle (orc_set_tri_lights): uniform point; the faces a path can hit emit */
+                        const float* tl = g_tri_lights + 12 * (size_t)(pick - n_el);
+                        v3 e1 = V(tl[4], tl[5], tl[6]), e2 = V(tl[8], tl[9], tl[10]);
+                        float su = sqrtf(u1);
+                        v3 pl = vmadd(e2, u2 * su, vmadd(e1, 1.0f - su, V(tl[0], tl[1], tl[2])));
+                        v3 w = vsub(pl, hitpos);
+                        float d2 = vdot(w, w);
+                        float dist = sqrtf(d2);
+                        v3 l = vscale(w, 1.0f / dist);
+                        float cosl = vdot(nl, l);
+                        float sdot = vdot(vcross(e1, e2), l);
+                        float proj = fabsf(sdot); /* 2 * area * cos(light) */
+                        float t_light = dist * 0.999f;
+                        /* with back-face culling a path only ever hits a triangle's front (det > 0 <=> cross(e1,e2).d < 0) */
+                        int blocked = !(cosl > 0.0f) || !(d2 > 0.0f) || !(proj > 0.0f) || (P->cull_backfaces != 0 && !(sdot < 0.0f));
+                        for (size_t j = 0; j < n_sph && !blocked; j++) {
+                            float ts = sphere_intersect(&sph[j], hitpos, l);
+                            if (ts != 0.0f && ts < t_light && ts > 0.01f) blocked = 1;
+                        }
+                        if (!blocked) {
+                            hit_t h2 = {F32_MAX, -1, {0, 0, 0}};
+                            if (nodes) h2 = bvh_intersect(nodes, tris, tidx, hitpos, l, P->cull_backfaces, cnt);
+                            else if (cnt) cnt->rays++;
+                            if (!(h2.t < t_light)) {
+                                float k = ((cosl * (0.5f * proj)) * (float)n_all) / (3.14159274f * d2);
+                                accu = vadd(accu, vscale(vmul(mask, V(tl[3], tl[7], tl[11])), k));
+                            }
+                        }
+                    } else {
                     int li = 0;
                     for (int i = 0, k = 0; i < 8; i++)
                         if ((el >> i) & 1u) { if (k == pick) { li = i; break; } k++; }
@@ -522,9 +563,10 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
                         if (nodes) h2 = bvh_intersect(nodes, tris, tidx, hitpos, l, P->cull_backfaces, cnt);
                         else if (cnt) cnt->rays++;
                         if (!(h2.t < t_light)) {
-                            float k = (cosl * (2.0f * (1.0f - cos_max))) * (float)n_el;
+                            float k = (cosl * (2.0f * (1.0f - cos_max))) * (float)n_all;
                             accu = vadd(accu, vscale(vmul(mask, V(L->emi[0], L->emi[1], L->emi[2])), k));
                         }
+                    }
                     }
                 }
             }

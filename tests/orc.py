@@ -48,6 +48,8 @@ def lib():
         L.orc_render_mat.restype = i32
         L.orc_render_mat.argtypes = [vp, vp, vp, vp, vp, C.POINTER(g.Sphere), sz, C.POINTER(g.Material), vp,
                                      C.POINTER(g.Camera), C.POINTER(g.Params), C.c_uint32, C.POINTER(g.Counters)]
+        L.orc_set_tri_lights.restype = None
+        L.orc_set_tri_lights.argtypes = [vp, sz]
         L.orc_primary_rays.restype = None
         L.orc_primary_rays.argtypes = [C.POINTER(g.Camera), i32, i32, C.c_uint64, i32, vp]
         _lib = L
@@ -58,9 +60,25 @@ def counters_dict(c):
     return {f: getattr(c, f) for f, _ in g.Counters._fields_}
 
 
-def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True, materials=None, tri_material=None):
+def tri_lights(mesh, materials, tri_material):
+    """The light list PT_FLAG_NEE uses with a material table: every triangle whose row emits, ascending id, as
+    (v0, emi.r) (e1 = v1 - v0, emi.g) (e2 = v2 - v0, emi.b) in binary32 — what the product copies out of its records."""
+    tm = np.asarray(tri_material, np.int64)
+    emi = np.array([[m.emi[0], m.emi[1], m.emi[2]] for m in materials], np.float32)
+    ids = np.nonzero(np.any(emi[tm] != 0, axis=1))[0]
+    v = np.asarray(mesh.verts, np.float32)[np.asarray(mesh.tris, np.int64)[ids]]   # [n, 3, 3]
+    out = np.zeros((len(ids), 12), np.float32)
+    out[:, 0:3] = v[:, 0]
+    out[:, 4:7] = v[:, 1] - v[:, 0]
+    out[:, 8:11] = v[:, 2] - v[:, 0]
+    out[:, 3], out[:, 7], out[:, 11] = emi[tm[ids]].T
+    return np.ascontiguousarray(out)
+
+
+def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True, materials=None, tri_material=None, lights=None):
     """CPU restatement of trace<<<>>> (tracer.cu:343-400).  Returns accum, rgba, counters.
-    materials / tri_material: the per-triangle material extension (pt_upload_tri_materials)."""
+    materials / tri_material: the per-triangle material extension (pt_upload_tri_materials); lights: tri_lights(...)
+    for PT_FLAG_NEE over emissive triangles."""
     W, H = params.width, params.height
     if accum is None:
         accum = np.zeros((H, W, 3), np.float32)
@@ -73,9 +91,11 @@ def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True, materia
     if materials is not None and len(materials):
         mtab = (g.Material * len(materials))(*materials)
         ids = np.ascontiguousarray(tri_material, np.int32)
+        lib().orc_set_tri_lights(lights.ctypes.data if lights is not None and len(lights) else None, len(lights) if lights is not None else 0)
         rc = lib().orc_render_mat(accum.ctypes.data, rgba.ctypes.data if want_rgba else None, nodes, tris, idx,
                                   spheres if n_s else None, n_s, mtab, ids.ctypes.data, C.byref(cam), C.byref(params),
                                   spp, C.byref(cnt))
+        lib().orc_set_tri_lights(None, 0)
     else:
         rc = lib().orc_render(accum.ctypes.data, rgba.ctypes.data if want_rgba else None, nodes, tris, idx,
                               spheres if n_s else None, n_s, C.byref(cam), C.byref(params), spp, C.byref(cnt))

@@ -285,3 +285,83 @@ def test_gpu_equals_oracle_with_estimator_switches(pt, flags):
         assert n_diff <= pt.max_diff
         if n_diff == 0:
             assert np.array_equal(r, rref)
+
+
+# ------------------------------------------------------------------------------ next-event estimation over emissive triangles
+NEE = g.FLAG_COSINE_DIFF | g.FLAG_NEE
+
+
+def test_oracle_nee_samples_the_light_quad():
+    """PT_FLAG_NEE with a material table: the emissive TRIANGLES are lights (CornellBox-Original's quad).  Same expectation
+    as gathering the light by chance (block means within Monte-Carlo error), much less noise, and the light list the
+    test hands the oracle is what the product derives (ids ascending, e1 = v1 - v0, e2 = v2 - v0)."""
+    mesh = g.scene_mesh("cornell_box")
+    bvh = g.Bvh(mesh)
+    # the running mean is clamped to [0, 1] (tracer.cu:389-391): dim the quad (17, 12, 4) so that no sample reaches the clamp
+    table = [material(tuple(m.col), emi=tuple(e / 40.0 for e in m.emi), mat=m.mat) for m in mesh.materials]
+    lights = orc.tri_lights(mesh, table, mesh.tri_material)
+    assert lights.shape == (2, 12) and np.all(lights[:, [3, 7, 11]] > 0)       # the quad = two triangles
+    W, H = 96, 72
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.bk_color[:] = (0, 0, 0)
+    p.depth = 5
+    kw = dict(materials=table, tri_material=mesh.tri_material)
+
+    def mean_of(flags, frames, spp, depth):
+        """unclamped statistics over independent frames + the largest value a pixel ever showed (the running mean clamps at 1)"""
+        tot, sq, top = np.zeros((H, W, 3)), np.zeros((H, W, 3)), np.zeros((H, W))
+        for f in range(frames):
+            p.flags, p.frame, p.sample_index, p.depth = flags, 1000 * f, 1, depth
+            a, _, _ = orc.render(bvh, None, cam, p, spp, lights=lights if flags & g.FLAG_NEE else None, **kw)
+            tot += a
+            sq += a.astype(np.float64) ** 2
+            top = np.maximum(top, a.max(axis=-1))
+        m = tot / frames
+        return m, sq / frames - m ** 2, top
+
+    # the box is open towards the camera: keep what a path gathered when it leaves (the reference kernel's miss throws it away,
+    # tracer.cu:140-142, which would make the picture depend on WHEN light is gathered)
+    # Every surface here is DIFF, so the light sample taken at hit k stands for the emission a bounce would find at hit k + 1:
+    # NEE with depth d has exactly the expectation of plain gathering with depth d + 1.
+    plain, var_plain, top_plain = mean_of(g.FLAG_COSINE_DIFF | g.FLAG_MISS_KEEPS_PATH, 480, 4, 5)
+    nee, var_nee, top_nee = mean_of(NEE | g.FLAG_MISS_KEEPS_PATH, 120, 4, 4)
+    # compare where neither estimator ever reached the clamp: that drops the pixels that look at the quad and the strip of
+    # ceiling right beside it, where the light sample's 1 / dist^2 spikes
+    sel = (top_plain < 0.9) & (top_nee < 0.9)
+    assert sel.mean() > 0.5
+    blocks = lambda a: np.array([a[y:y + 12, x:x + 12][sel[y:y + 12, x:x + 12]].mean() for y in range(0, H, 12) for x in range(0, W, 12)
+                                 if sel[y:y + 12, x:x + 12].sum() > 40])
+    bp, bn = blocks(plain), blocks(nee)
+    rel = np.abs(bn - bp) / np.maximum(bp, 0.25 * bp.mean())
+    print(f"NEE over triangles: {len(bp)} blocks, max rel diff {rel.max():.3f}, mean {plain[sel].mean():.4f} vs {nee[sel].mean():.4f}; "
+          f"variance ratio {var_plain[sel].mean() / var_nee[sel].mean():.1f}")
+    assert abs(nee[sel].mean() - plain[sel].mean()) < 0.03 * plain[sel].mean()
+    assert rel.max() < 0.15
+    assert var_nee[sel].mean() < 0.5 * var_plain[sel].mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,spheres", [("cornell_box", False), ("cornell_box_dragon", True)])
+def test_gpu_nee_over_emissive_triangles_equals_oracle(pt, scene, spheres):
+    """Every kernel setting, bit for bit: pick among eligible spheres + emissive triangles, shadow ray, no double count."""
+    mesh = g.scene_mesh(scene)
+    bvh = g.Bvh(mesh)
+    sph = g.reference_spheres() if spheres else None
+    if sph:
+        for s in sph[:6]:
+            s.emi[:] = (0, 0, 0)          # walls dark: the lamp sphere and the quad are the lights
+    lights = orc.tri_lights(mesh, mesh.materials, mesh.tri_material)
+    W, H, spp = 200, 150, 3
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.depth, p.frame, p.flags = 5, 7, NEE | g.FLAG_WRITE_RGBA
+    p.bk_color[:] = (0, 0, 0)
+    ref, rref, cnt = orc.render(bvh, sph, cam, p, spp, materials=mesh.materials, tri_material=mesh.tri_material, lights=lights)
+    a, r = _gpu(pt, bvh, sph, cam, p, spp, mesh.materials, mesh.tri_material)
+    n_diff = int(np.any(a != ref, axis=-1).sum())
+    print(f"{scene}: {len(lights)} triangle lights, differing pixels {n_diff} of {W * H}; mean {a.mean():.4f}; rays/path {cnt['rays'] / cnt['paths']:.2f}")
+    assert n_diff <= pt.max_diff
+    if n_diff == 0:
+        assert np.array_equal(r, rref)
+    assert a.mean() > 0.01
+    # without the table the flag falls back to the spheres alone (and to nothing at all without spheres)
+    pt.upload_tri_materials(None, None)
