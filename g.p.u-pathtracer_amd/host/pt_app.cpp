@@ -7,7 +7,7 @@
 // Usage: pt_app --mesh assets/cornell.ptmesh [--width 1280 --height 720 --frames 16 --spp 1
 //               --depth 4 --mat 0..3 --no-spheres --no-materials --bk r g b --device 0
 //               --out image.ppm|.png|.pfm  --checkpoint state.ckpt [--checkpoint-every N]
-//               --resume state.ckpt --device-build --fix-estimators --gpus N --tile ROWS]
+//               --resume state.ckpt --device-build --fix-estimators --nee --gpus N --tile ROWS]
 // --gpus N splits the framebuffer over N contexts, one per GPU (devices device, device+1, ... modulo the number
 // present, so N > 1 also runs on a one-GPU box): stripes of --tile rows (default 8) are dealt round-robin
 // (pt_params.part_*), every context holds the whole scene and renders only its stripes of every frame — the random
@@ -39,7 +39,7 @@ static int die(const char* what, const char* msg) {
 int main(int argc, char** argv) {
     std::string mesh_path, out_path, ckpt_path, resume_path;
     int W = 1280, H = 720, frames = 16, depth = 4, mat = PT_MAT_DIFF, device = 0, spp = 1, ckpt_every = 0, gpus = 1, tile = 8;
-    bool spheres = true, use_materials = true, device_build = false, fix_estimators = false;
+    bool spheres = true, use_materials = true, device_build = false, fix_estimators = false, nee = false;
     float bk[3] = {1.f, 1.f, 1.f};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
         else if (a == "--no-materials") use_materials = false;
         else if (a == "--device-build") device_build = true;
         else if (a == "--fix-estimators") fix_estimators = true;
+        else if (a == "--nee") nee = true;   // next-event estimation (implies the cosine-weighted DIFF lobe and keeps a path's light on a miss)
         else if (a == "--spp") spp = std::atoi(next("--spp"));
         else if (a == "--checkpoint") ckpt_path = next("--checkpoint");
         else if (a == "--checkpoint-every") ckpt_every = std::atoi(next("--checkpoint-every"));
@@ -150,6 +151,7 @@ int main(int argc, char** argv) {
     p.air_ior = 1.0f; p.glass_ior = 1.4f; p.phong_expo = 30.f;
     p.flags = PT_FLAG_WRITE_RGBA;
     if (fix_estimators) p.flags |= PT_FLAG_FACE_FORWARD | PT_FLAG_COSINE_DIFF | PT_FLAG_GLASS_FIX | PT_FLAG_RUSSIAN_ROULETTE;
+    if (nee) p.flags |= PT_FLAG_COSINE_DIFF | PT_FLAG_NEE | PT_FLAG_MISS_KEEPS_PATH;
     p.part_count = gpus; p.part_rows = tile;
 
     // every context owns full-frame buffers (accum/rgba are always addressed by the global pixel); it touches only
@@ -178,7 +180,7 @@ int main(int argc, char** argv) {
 
     // what a checkpoint must agree on to be continued: geometry size, image size, the scalar parameters
     uint64_t tag = pth_frame_hash((uint64_t)pth_mesh_n_tris(mesh) * 1315423911ull + (uint64_t)W * 65537u + (uint64_t)H);
-    tag = pth_frame_hash(tag ^ ((uint64_t)depth << 32 | (uint64_t)mat << 8 | (fix_estimators ? 4u : 0u) | (spheres ? 2u : 0u) | (has_materials ? 1u : 0u)));
+    tag = pth_frame_hash(tag ^ ((uint64_t)depth << 32 | (uint64_t)mat << 8 | (fix_estimators ? 4u : 0u) | (nee ? 8u : 0u) | (spheres ? 2u : 0u) | (has_materials ? 1u : 0u)));
 
     uint64_t frameNumber = 0, constantPdf = 0;   // constantPdf = samples folded so far
     std::vector<float> host_acc;

@@ -142,3 +142,21 @@ def test_app_tile_split_over_contexts_is_bit_identical(tmp_path):
     run(["--gpus", "2", "--out", str(tmp_path / "two.png")])
     run(["--out", str(tmp_path / "one.png")])
     assert np.array_equal(decode_png(tmp_path / "two.png"), decode_png(tmp_path / "one.png"))
+
+
+@pytest.mark.gpu
+def test_app_nee_renders_the_lit_box_with_less_noise(tmp_path):
+    """pt_app --nee on CornellBox-Original (the light is the .mtl's emissive quad): at 4 spp the picture is several times
+    closer to the converged one (64 spp) than 4 spp of finding the light by chance — compared below the display clamp."""
+    mesh = os.path.join(ROOT, "assets", "cornell_box.ptmesh")
+    common = [APP, "--mesh", mesh, "--width", "160", "--height", "120", "--depth", "4", "--no-spheres", "--bk", "0", "0", "0"]
+    run = lambda extra: subprocess.run(common + extra, check=True, capture_output=True, text=True, timeout=300).stdout
+    run(["--nee", "--frames", "64", "--spp", "16", "--out", str(tmp_path / "nee.pfm")])
+    run(["--nee", "--frames", "4", "--spp", "4", "--out", str(tmp_path / "nee4.pfm")])
+    run(["--fix-estimators", "--frames", "4", "--spp", "4", "--out", str(tmp_path / "plain4.pfm")])
+    ref, nee4, plain4 = read_pfm(tmp_path / "nee.pfm"), read_pfm(tmp_path / "nee4.pfm"), read_pfm(tmp_path / "plain4.pfm")
+    dim = ref.max(axis=-1) < 0.5
+    assert dim.mean() > 0.4 and ref[dim].mean() > 0.02
+    err_nee, err_plain = np.abs(nee4 - ref)[dim].mean(), np.abs(plain4 - ref)[dim].mean()
+    print(f"4 spp against the 64-spp NEE picture: mean abs error {err_nee:.4f} with --nee, {err_plain:.4f} without")
+    assert err_nee < 0.5 * err_plain
