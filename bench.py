@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-cpu-reference", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (materials, 1 spp, device tree, big scene, gather bound)")
     ap.add_argument("--device-build", action="store_true", help="build the BVH on the device (pt_build_bvh) instead of the host SBVH builder")
+    ap.add_argument("--keep-hierarchy", action="store_true",
+                    help="PT_OPT_REBUILD 0: walk the uploaded hierarchy whatever it costs (default: PT_OPT_REBUILD 2, the upload also "
+                         "re-clusters the triangles on the device and keeps the tree with the smaller area cost in node visits)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still initialise torch.distributed over RCCL (backend nccl, world 1) and send every step's "
                          "display words through the same all_gather_into_tensor / side-stream path the N > 1 runs use")
@@ -231,12 +234,24 @@ def main():
     if a.batch:
         pt.set_option(g.OPT_BATCH, a.batch)
         pt.set_option(g.OPT_WAVE_BATCH, a.batch)
+    tree_note = "built on the device (pt_build_bvh, PLOC)"
     if a.device_build:
         pt.build_bvh(mesh)
     else:
+        # the reference's flow: hierarchy built on the host (SBVH port), flattened, uploaded.  PT_OPT_REBUILD 2: the upload keeps
+        # the caller's triangles and whichever hierarchy — the caller's or the device's re-clustered one — is cheaper to walk
+        pt.set_option(g.OPT_REBUILD, 0 if a.keep_hierarchy else 2)
         pt.upload_bvh(bvh)
+        pt.set_option(g.OPT_REBUILD, 0)
+        tree_note = ("host SBVH hierarchy, uploaded (PT_OPT_REBUILD 0)" if a.keep_hierarchy else
+                     "host SBVH hierarchy uploaded with PT_OPT_REBUILD 2: kept " +
+                     ("the device's re-clustered tree" if pt.last_build_ms() > 0 else "the uploaded hierarchy"))
     pt.upload_spheres(sph)
     info = pt.scene_info()
+    try:
+        tree_cost = pt.tree_cost()
+    except Exception:
+        tree_cost = None
 
     # full-frame buffers, height padded so that the stripes split evenly over the ranks
     from gpu_pathtracer_amd import tile_split
@@ -403,7 +418,8 @@ def main():
                                    f"{'reference 8-sphere room' if n_sph else 'no spheres'}, {a.spp} spp per step",
                        "kernel": KERNEL_NAMES.get(a.kernel, str(a.kernel)),
                        "bvh": {"inner": info["n_inner"], "tri_refs": info["n_tri_refs"], "max_depth": info["max_depth"],
-                               "device_mb": round(info["device_bytes"] / 2 ** 20, 1), "built_on": "device" if a.device_build else "host"},
+                               "device_mb": round(info["device_bytes"] / 2 ** 20, 1), "built_on": "device" if a.device_build else "host", "tree": tree_note,
+                               "area_cost_node_visits": None if tree_cost is None else round(tree_cost[0], 3)},
                        "parallelism": (f"tile-split x{world} ({rows}-row stripes, RCCL all-gather of RGBA8 every step"
                                        f"{', overlapped with the next render' if overlap else ''})") if use_dist else "1 GPU",
                        "closed_scene": bool(closed), "rays_per_step": rays_per_step,
@@ -512,6 +528,11 @@ def main():
         # side measurement: the same workload over a tree built ON the device
         # (pt_build_bvh); done last, it replaces the scene of this context
         n_x = max(5, a.steps // 5)
+        if bvh is not None and not a.keep_hierarchy:   # the uploaded hierarchy itself, whatever PT_OPT_REBUILD 2 decided
+            pt.upload_bvh(bvh)
+            settle()
+            out["mrays_per_s_uploaded_hierarchy"] = rate(n_x, timed(n_x, 1))
+            out["area_cost_node_visits_uploaded_hierarchy"] = round(pt.tree_cost()[0], 3)
         build_ms = min(pt.build_bvh(mesh) for _ in range(3))
         settle()
         out["device_bvh_build_ms"] = round(build_ms, 2)          # PLOC (the default PT_OPT_BUILD_ALGO)

@@ -108,6 +108,7 @@ PTMI_SYMBOLS = [
     ("pt_last_kernel_ms", _i, [_vp, C.POINTER(C.c_float)]),
     ("pt_get_stage_ms", _i, [_vp, C.POINTER(C.c_float), _i]),
     ("pt_auto_choice", _i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("pt_tree_cost", _i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("pt_scene_info", _i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
 ]

@@ -37,6 +37,30 @@ static void dbg_segv(int sig) {
 using namespace ptmi;
 
 namespace ptmi {
+static int tree_cost_impl(pt_ctx* c, double* node_visits, double* tri_tests);
+
+// everything on the context that describes the acceleration structure (PT_OPT_REBUILD 2 holds two for a moment)
+struct TreeState {
+    float4 *d_nodes, *d_tris;
+    bool records_woop, has_bvh;
+    uint64_t wide_root, n_wide, n_inner, n_refs, n_leaves, scene_bytes;
+    uint32_t wide_top_layout, wide_depth, n_top_layout, max_depth;
+    int32_t max_tri_id;
+    float build_ms;
+    static TreeState of(const pt_ctx* c) {
+        return {c->d_nodes, c->d_tris, c->records_woop, c->has_bvh, c->wide_root, c->n_wide, c->n_inner, c->n_refs, c->n_leaves, c->scene_bytes,
+                c->wide_top_layout, c->wide_depth, c->n_top_layout, c->max_depth, c->max_tri_id, c->build_ms};
+    }
+    void restore(pt_ctx* c) const {
+        c->d_nodes = d_nodes; c->d_tris = d_tris; c->records_woop = records_woop; c->has_bvh = has_bvh;
+        c->wide_root = wide_root; c->n_wide = n_wide; c->n_inner = n_inner; c->n_refs = n_refs; c->n_leaves = n_leaves; c->scene_bytes = scene_bytes;
+        c->wide_top_layout = wide_top_layout; c->wide_depth = wide_depth; c->n_top_layout = n_top_layout; c->max_depth = max_depth;
+        c->max_tri_id = max_tri_id; c->build_ms = build_ms;
+    }
+};
+}  // namespace ptmi
+
+namespace ptmi {
 int stage_mark(pt_ctx* c, int kind) {
     if (!c->opt_timing) return PT_OK;
     if (c->stage_used == c->stage_ev.size()) {
@@ -157,7 +181,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             c->opt_walk = value;
             return PT_OK;
         case PT_OPT_SPHERE_LDS: c->opt_sph_lds = value != 0; return PT_OK;
-        case PT_OPT_REBUILD: c->opt_rebuild = value != 0; return PT_OK;
+        case PT_OPT_REBUILD:
+            if (value < 0 || value > 2) return fail(c, PT_ERR_INVALID, "pt_set_option: rebuild must be 0 (keep the hierarchy), 1 (re-cluster) or 2 (keep the cheaper tree)");
+            c->opt_rebuild = value;
+            return PT_OK;
         case PT_OPT_PRESPLIT:
             if (value < 0 || value > 100000) return fail(c, PT_ERR_INVALID, "pt_set_option: presplit must be 0 (off) .. 100000 (per cent of diag/sqrt(n))");
             c->opt_presplit = value;
@@ -263,7 +290,8 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     for (const ptscene::Ref& r : T.refs) max_id = std::max(max_id, r.id);
     if (c->d_tri_matid && (size_t)max_id >= c->n_tri_matid)
         return fail(c, PT_ERR_INVALID, "pt_upload_bvh: the triangle-material array on this context does not cover this BVH's triangle ids (clear or re-upload it first)");
-    if (c->opt_rebuild && c->opt_tri_test == 0) {
+    const int rebuild = c->opt_tri_test == 0 ? c->opt_rebuild : 0;
+    auto recluster = [&]() -> int {
         // PT_OPT_REBUILD: keep the caller's TRIANGLES, not its hierarchy — the distinct triangles of the
         // Compact arrays (a spatial-split builder lists some more than once, each time in full) are
         // clustered again on the device (pt_build.h).  The closest hit does not depend on the tree, so the
@@ -288,7 +316,8 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
         if (rc != PT_OK && too_deep && c->opt_build_algo == 1)
             rc = build_bvh_impl(c, verts.data(), verts.size() / 3, tri_rows.data(), ids.size(), 0, &too_deep, ids.data());
         return rc;
-    }
+    };
+    if (rebuild == 1) return recluster();
     ptscene::refine(T, (uint32_t)c->opt_leaf_max);
     ptscene::Output O;
     ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
@@ -321,7 +350,26 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     c->scene_bytes = nb + tb + wb;
     c->max_tri_id = max_id;
     c->has_bvh = true;
+    c->build_ms = -1.f;   // an uploaded hierarchy: no device build stands behind this tree
     c->scene_gen++;
+    if (rebuild == 2 && c->n_wide > 0) {
+        // PT_OPT_REBUILD 2: the caller's hierarchy is up; build the re-clustered one beside it and keep whichever costs a
+        // random ray fewer wide-node visits (pt_tree_cost).  A failure on the way leaves the caller's tree in place.
+        double cost_a = 0.0, cost_b = 0.0, unused = 0.0;
+        if (tree_cost_impl(c, &cost_a, &unused) != PT_OK) return PT_OK;
+        const TreeState mine = TreeState::of(c);
+        c->d_nodes = nullptr;   // the builder frees the context's buffer before it installs its own
+        c->d_tris = nullptr;
+        const bool built = recluster() == PT_OK && c->d_nodes != nullptr;
+        if (built && tree_cost_impl(c, &cost_b, &unused) == PT_OK && cost_b < cost_a) {
+            (void)hipFree(mine.d_nodes);
+        } else {
+            if (c->d_nodes != mine.d_nodes) (void)hipFree(c->d_nodes);
+            mine.restore(c);
+            c->err.clear();
+        }
+        c->scene_gen++;
+    }
     return PT_OK;
 }
 
@@ -338,7 +386,7 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
 
 int pt_last_build_ms(pt_ctx* c, float* ms) {
     if (!c || !ms) return fail(c, PT_ERR_INVALID, "pt_last_build_ms: null argument");
-    if (c->build_ms < 0.f) return fail(c, PT_ERR_INVALID, "pt_last_build_ms: no pt_build_bvh on this context yet");
+    if (c->build_ms < 0.f) return fail(c, PT_ERR_INVALID, "pt_last_build_ms: the tree on this context was not built on the device");
     *ms = c->build_ms;
     return PT_OK;
 }
@@ -693,6 +741,88 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe + 1], c->stream));
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
     return PT_OK;
+}
+
+// pt_tree_cost: one lane per wide node; out[0] = root area, out[1] = sum of inner-child areas, out[2] = sum of leaf area x records
+// (per-block partial sums, added up on the host in block order: the figure is reproducible, so a choice made on it is too)
+__global__ void __launch_bounds__(256) k_tree_cost(const float4* __restrict__ items, uint64_t wide_root, uint32_t n_wide, double* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    double inner = 0.0, leaf = 0.0, root = 0.0;
+    if (i < n_wide) {
+        const float4* nd = items + wide_root + 4 * (size_t)i;
+        const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        const float sc[3] = {q0.w, q3.z, q3.w};
+        const uint32_t ql[3] = {__float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z)};
+        const uint32_t qh[3] = {__float_as_uint(q1.w), __float_as_uint(q2.x), __float_as_uint(q2.y)};
+        const int link[4] = {__float_as_int(q2.z), __float_as_int(q2.w), __float_as_int(q3.x), __float_as_int(q3.y)};
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int k = 0; k < 4; k++) {
+            float d[3];
+            bool used = true;
+            for (int a = 0; a < 3; a++) {
+                const int l = (int)((ql[a] >> (8 * k)) & 0xffu), h = (int)((qh[a] >> (8 * k)) & 0xffu);
+                if (l > h) used = false;   // an unused slot holds an inverted box
+                d[a] = (float)(h - l) * sc[a];
+                if (l <= h) { lo[a] = fminf(lo[a], (float)l * sc[a]); hi[a] = fmaxf(hi[a], (float)h * sc[a]); }
+            }
+            if (!used) continue;
+            const double area = 2.0 * ((double)d[0] * d[1] + (double)d[1] * d[2] + (double)d[2] * d[0]);
+            if (link[k] >= 0) {
+                inner += area;
+            } else {
+                int n = 0;
+                for (size_t r = (size_t)(~link[k]);; r += 4) {
+                    n++;
+                    if (__float_as_int(items[r + 1].w) != 0 || n >= 64) break;   // the record's `last` flag
+                }
+                leaf += area * (double)n;
+            }
+        }
+        if (i == 0) {
+            const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            root = 2.0 * (dx * dy + dy * dz + dz * dx);
+        }
+    }
+    // block reduction through LDS, one atomic per block and term
+    __shared__ double s_in[256], s_lf[256];
+    s_in[threadIdx.x] = inner; s_lf[threadIdx.x] = leaf;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { s_in[threadIdx.x] += s_in[threadIdx.x + off]; s_lf[threadIdx.x] += s_lf[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[1 + 2 * (size_t)blockIdx.x] = s_in[0]; out[2 + 2 * (size_t)blockIdx.x] = s_lf[0]; }
+    if (i == 0) out[0] = root;
+}
+
+namespace ptmi {
+static int tree_cost_impl(pt_ctx* c, double* node_visits, double* tri_tests) {
+    const unsigned n_blocks = (unsigned)((c->n_wide + 255) / 256);
+    const size_t n_out = 1 + 2 * (size_t)n_blocks;
+    double* d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_out, n_out * sizeof(double)));
+    hipLaunchKernelGGL(k_tree_cost, dim3(n_blocks), dim3(256), 0, c->stream, c->d_nodes, c->wide_root, (uint32_t)c->n_wide, d_out);
+    hipError_t e = hipGetLastError();
+    std::vector<double> h(n_out, 0.0);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(c, e, "pt_tree_cost");
+    if (!(h[0] > 0.0)) return fail(c, PT_ERR_INVALID, "pt_tree_cost: degenerate root box");
+    double inner = 0.0, leaf = 0.0;
+    for (unsigned b = 0; b < n_blocks; b++) { inner += h[1 + 2 * (size_t)b]; leaf += h[2 + 2 * (size_t)b]; }
+    *node_visits = (h[0] + inner) / h[0];
+    *tri_tests = leaf / h[0];
+    return PT_OK;
+}
+}  // namespace ptmi
+
+int pt_tree_cost(pt_ctx* c, double* node_visits, double* tri_tests) {
+    if (!c || !node_visits || !tri_tests) return fail(c, PT_ERR_INVALID, "pt_tree_cost: null argument");
+    if (!c->has_bvh || c->wide_root == 0 || c->n_wide == 0) return fail(c, PT_ERR_NO_SCENE, "pt_tree_cost: no 4-wide tree on this context");
+    if (c->records_woop) return fail(c, PT_ERR_UNSUPPORTED, "pt_tree_cost: reads the Moller-Trumbore records' leaf terminators");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return tree_cost_impl(c, node_visits, tri_tests);
 }
 
 int pt_auto_choice(pt_ctx* c, int* kernel, float* ms_persistent, float* ms_wavefront) {

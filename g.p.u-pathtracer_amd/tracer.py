@@ -164,11 +164,24 @@ class PathTracer:
         self._check(self._lib.pt_auto_choice(self._ctx, C.byref(k), C.byref(a), C.byref(b)))
         return k.value, a.value, b.value
 
+    def tree_cost(self):
+        """(expected wide-node visits, expected triangle tests) of a random ray: surface-area cost of the 4-wide tree."""
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.pt_tree_cost(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def wave_stats(self):
         out = (C.c_uint64 * 10)()
         self._check(self._lib.pt_get_wave_stats(self._ctx, out, 10))
         names = ("it_node", "act_node", "it_rec", "act_rec", "it_shade", "act_shade", "it_begin", "act_begin", "it_loop", "stack_overflows")
         return dict(zip(names, [int(v) for v in out]))
+
+    def last_build_ms(self):
+        """Device time of the build behind the tree on the context; -1 when it is an uploaded hierarchy."""
+        ms = C.c_float()
+        if self._lib.pt_last_build_ms(self._ctx, C.byref(ms)) != 0:
+            return -1.0
+        return ms.value
 
     def last_kernel_ms(self):
         ms = C.c_float()

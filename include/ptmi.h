@@ -166,8 +166,13 @@ enum {
                                  degenerate input falls back to 0), 0 = LBVH (Karras hierarchy: 1.8 ms, a
                                  tree that traces ~14 % slower)                                    */
     PT_OPT_REBUILD = 17,      /* pt_upload_bvh: 1 = keep the uploaded TRIANGLES but build the hierarchy again on
-                                 the device (PT_OPT_BUILD_ALGO); same images bit for bit; faster or slower
-                                 than the caller's tree depending on the scene; default 0             */
+                                 the device (PT_OPT_BUILD_ALGO); same images (the closest hit does not depend
+                                 on the tree); faster or slower than the caller's tree depending on the scene.
+                                 2 = build it as well and keep whichever 4-wide tree has the smaller area cost
+                                 in node visits (pt_tree_cost: the term that tracks the measured frame time,
+                                 DESIGN.md 5.5) — the caller's on architectural scenes with long triangles
+                                 that its spatial splits cut, the re-clustered one on dense scans; costs one
+                                 device build (7 ms for 800 k triangles) per upload.  Default 0           */
     PT_OPT_PRESPLIT = 18,     /* pt_build_bvh / PT_OPT_REBUILD: 0 (default) = off; v > 0 = triangles longer than
                                  v per cent of (scene diagonal / sqrt(n triangles)) enter the builder as up
                                  to 8 primitives, one per slab of their box (early split clipping)      */
@@ -282,7 +287,8 @@ int pt_upload_spheres(pt_ctx* ctx, const pt_sphere* spheres, size_t n_spheres);
  * on the tree).  Triangle ids are the row numbers of `tris`.  PT_OPT_LEAF_MAX (default 2)
  * = triangles per leaf.  verts: float[n_verts][3], tris: int32[n_tris][3]; host arrays, copied. */
 int pt_build_bvh(pt_ctx* ctx, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris);
-int pt_last_build_ms(pt_ctx* ctx, float* ms_out);   /* device time of the last pt_build_bvh */
+int pt_last_build_ms(pt_ctx* ctx, float* ms_out);   /* device time of the build behind the tree on the context (pt_build_bvh or a
+                                                       kept PT_OPT_REBUILD tree); PT_ERR_INVALID for an uploaded hierarchy */
 
 /* Per-triangle materials — an EXTENSION.  The reference parses the .mtl into
  * `materials` but never reads it (utilfun.cpp:458-462) and shades every triangle with the ONE
@@ -347,6 +353,11 @@ int pt_get_stage_ms(pt_ctx* ctx, float* out, int n);
 /* PT_KERNEL_AUTO's pick for the configuration of the last pt_render: *kernel = PT_KERNEL_PERSISTENT or
  * PT_KERNEL_WAVEFRONT once decided (PT_KERNEL_AUTO while the two trials are still running), and the two trial times. */
 int pt_auto_choice(pt_ctx* ctx, int* kernel, float* ms_persistent, float* ms_wavefront);
+/* Surface-area cost of the 4-wide tree on the context (measurement; what a random ray is expected to fetch):
+ * *node_visits = (area of the root + of every child box that leads to a wide node) / area of the root,
+ * *tri_tests   = sum over leaves of (area of the leaf's box x its triangle records) / area of the root.
+ * Areas are those of the quantised boxes the walk tests.  Synchronises the context's stream. */
+int pt_tree_cost(pt_ctx* ctx, double* node_visits, double* tri_tests);
 int pt_scene_info(pt_ctx* ctx, uint64_t* n_inner, uint64_t* n_tri_refs,
                   uint64_t* n_leaves, uint32_t* max_depth, uint64_t* device_bytes);
 

@@ -17,14 +17,18 @@ from test_gpu_parity import gpu_render, l2, bvh_of
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["default", "wavefront", "persistent"])
+@pytest.fixture(scope="module", params=["default", "cheaper-tree", "wavefront", "persistent"])
 def ptd(request):
-    """default = whatever PT_KERNEL_AUTO picks (what bench.py times); the two stage layouts named too."""
+    """default = whatever PT_KERNEL_AUTO picks; cheaper-tree = the same with PT_OPT_REBUILD 2, which is what bench.py times
+    (the upload keeps whichever of the caller's and the re-clustered hierarchy costs fewer node visits); the two stage
+    layouts named too."""
     t = g.PathTracer(0)
     if request.param == "wavefront":
         t.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
     elif request.param == "persistent":
         t.set_option(g.OPT_KERNEL, g.KERNEL_PERSISTENT)
+    elif request.param == "cheaper-tree":
+        t.set_option(g.OPT_REBUILD, 2)
     t.variant = request.param
     yield t
     t.close()

@@ -253,3 +253,48 @@ def test_upload_with_rebuild_is_bit_identical(pt, scene):
             assert info["n_tri_refs"] == mesh.n_tris          # duplicates folded
     assert int(np.any(frames[0] != ref, axis=-1).sum()) <= pt.max_diff
     assert int(np.any(frames[1] != ref, axis=-1).sum()) <= pt.max_diff
+
+
+def test_rebuild_2_keeps_the_cheaper_tree():
+    """PT_OPT_REBUILD 2: the uploaded hierarchy AND the re-clustered one are built, the one whose 4-wide tree costs a random
+    ray fewer node visits (pt_tree_cost) stays.  gto_sixteen (long triangles the host builder's spatial splits cut): the
+    caller's; the 32-triangle cornell box: the re-clustered one.  The choice is reproducible, the picture is the oracle's."""
+    t = g.PathTracer(0)
+    try:
+        for scene, expect_rebuilt in (("gto_sixteen", False), ("cornell", True)):
+            mesh = g.scene_mesh(scene)
+            bvh = g.Bvh(mesh)
+            costs = {}
+            for mode in (0, 1, 2, 2):
+                t.set_option(g.OPT_REBUILD, mode)
+                t.upload_bvh(bvh)
+                costs.setdefault(mode, []).append((t.tree_cost(), t.scene_info()))
+            t.set_option(g.OPT_REBUILD, 0)
+            (c0, i0), (c1, i1) = costs[0][0], costs[1][0]
+            (c2, i2), (c2b, i2b) = costs[2]
+            print(f"{scene}: node visits {c0[0]:.3f} uploaded, {c1[0]:.3f} re-clustered -> kept {c2[0]:.3f}")
+            assert (c1[0] < c0[0]) == expect_rebuilt
+            assert c2 == (c1 if expect_rebuilt else c0) and i2 == (i1 if expect_rebuilt else i0)
+            assert c2b == c2 and i2b == i2                                   # reproducible
+            assert c2[0] == min(c0[0], c1[0])
+            # the kept tree renders the oracle's picture
+            t.set_option(g.OPT_REBUILD, 2)
+            t.upload_bvh(bvh)
+            t.set_option(g.OPT_REBUILD, 0)
+            W, H = 320, 200
+            cam, p = g.default_camera(W, H), g.default_params(W, H)
+            p.frame = 3
+            sph = g.reference_spheres()
+            t.upload_spheres(sph)
+            ref, _, _ = orc.render(bvh, sph, cam, p, 2)
+            acc, rgba = t.alloc_frame(W, H)
+            t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 2)
+            t.sync()
+            a = acc.download(np.float32, (H, W, 3))
+            acc.free()
+            rgba.free()
+            assert int(np.any(a != ref, axis=-1).sum()) <= 2
+        with pytest.raises(g.PtError):
+            t.set_option(g.OPT_REBUILD, 3)
+    finally:
+        t.close()

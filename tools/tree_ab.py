@@ -52,7 +52,8 @@ for scene in a.scenes.split(","):
     cam = g.default_camera(W, H)
     if scene == "dragon":
         cam.dist = 18.0
-    rows = [("host tree (upload)", dict(upload=True)), ("upload + PT_OPT_REBUILD", dict(upload=True, rebuild=1))]
+    rows = [("host tree (upload)", dict(upload=True)), ("upload + PT_OPT_REBUILD 1", dict(upload=True, rebuild=1)),
+            ("upload + PT_OPT_REBUILD 2 (cheaper)", dict(upload=True, rebuild=2))]
     for lm in a.leaf_max.split(",") if a.leaf_max else ():
         rows.append((f"host tree, PT_OPT_LEAF_MAX {lm}", dict(upload=True, leaf_max=int(lm))))
     for ps in a.presplit.split(","):
@@ -77,6 +78,7 @@ for scene in a.scenes.split(","):
                 b_ms = pt.build_bvh(mesh)
             pt.upload_spheres(sph)
             info = pt.scene_info()
+            sah = pt.tree_cost()
             acc, rgba = pt.alloc_frame(W, H)
             ms = timed(pt, a.spp, acc, rgba, cam, a.frames)
             img = acc.download(np.float32, (H, W, 3))
@@ -84,4 +86,4 @@ for scene in a.scenes.split(","):
             crc = k if crc is None else (crc if crc == k else -1)
             out.append(f"{kname} {ms:7.3f} ms")
             pt.close()
-        print(f"  {name:34s} {info['device_bytes'] / 2 ** 20:7.1f} MB  build {b_ms:6.2f} ms  " + "  ".join(out) + f"  image crc {crc:#010x}")
+        print(f"  {name:34s} {info['device_bytes'] / 2 ** 20:7.1f} MB  build {b_ms:6.2f} ms  " + "  ".join(out) + f"  area cost {sah[0]:6.2f} nodes + {sah[1]:5.2f} tris  image crc {crc:#010x}")
