@@ -420,8 +420,9 @@ def main():
                        "bvh": {"inner": info["n_inner"], "tri_refs": info["n_tri_refs"], "max_depth": info["max_depth"],
                                "device_mb": round(info["device_bytes"] / 2 ** 20, 1), "built_on": "device" if a.device_build else "host", "tree": tree_note,
                                "area_cost_node_visits": None if tree_cost is None else round(tree_cost[0], 3)},
-                       "parallelism": (f"tile-split x{world} ({rows}-row stripes, RCCL all-gather of RGBA8 every step"
-                                       f"{', overlapped with the next render' if overlap else ''})") if use_dist else "1 GPU",
+                       "parallelism": (f"tile-split x{world} ({rows}-row stripes, "
+                                       f"{'REHEARSAL: all ranks on one GPU, gloo all-gather through host memory' if a.rehearse else 'RCCL all-gather'}"
+                                       f" of RGBA8 every step{', overlapped with the next render' if overlap else ''})") if use_dist else "1 GPU",
                        "closed_scene": bool(closed), "rays_per_step": rays_per_step,
                        "tile_split_equals_single_gpu": merged_ok},
             "stage_ms": {k: round(v, 4) for k, v in stage.items() if v > 0},
