@@ -261,6 +261,8 @@ def test_rebuild_2_keeps_the_cheaper_tree():
     caller's; the 32-triangle cornell box: the re-clustered one.  The choice is reproducible, the picture is the oracle's."""
     t = g.PathTracer(0)
     try:
+        with pytest.raises(g.PtError):
+            t.tree_cost()                                                    # nothing uploaded yet
         for scene, expect_rebuilt in (("gto_sixteen", False), ("cornell", True)):
             mesh = g.scene_mesh(scene)
             bvh = g.Bvh(mesh)
