@@ -58,6 +58,8 @@ for scene in a.scenes.split(","):
         rows.append((f"host tree, PT_OPT_LEAF_MAX {lm}", dict(upload=True, leaf_max=int(lm))))
     for ps in a.presplit.split(","):
         rows.append((f"pt_build_bvh PLOC presplit {ps}", dict(algo=1, presplit=int(ps))))
+    for lm in a.leaf_max.split(",") if a.leaf_max else ():
+        rows.append((f"pt_build_bvh PLOC, PT_OPT_LEAF_MAX {lm}", dict(algo=1, presplit=0, leaf_max=int(lm))))
     rows.append(("pt_build_bvh LBVH", dict(algo=0, presplit=0)))
     print(f"== {scene}: {len(mesh.tris)} triangles, {W}x{H}, {a.spp} spp per call (host build {host_s:.1f} s)")
     for name, o in rows:
@@ -73,6 +75,7 @@ for scene in a.scenes.split(","):
                 pt.upload_bvh(bvh)
                 b_ms = -1.0
             else:
+                pt.set_option(g.OPT_LEAF_MAX, o.get("leaf_max", 2))
                 pt.set_option(g.OPT_BUILD_ALGO, o["algo"])
                 pt.set_option(g.OPT_PRESPLIT, o["presplit"])
                 b_ms = pt.build_bvh(mesh)
