@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
         // ---- walk until `batch` lanes have finished (lanes that can get no more work do not count)
         const int n_dead = empty ? 64 - __popcll(busy) : 0;
         if (live) {
-            const bool fin = trav_run_wide<COUNT, true, false>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
+            const bool fin = trav_run_wide<COUNT, true, false, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
             if (fin) {
                 P.wf.hit[idx] = make_float2(ts.h.t, __int_as_float(ts.h.rec));
                 live = false;

@@ -159,7 +159,7 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
             if (ALG >= 2) {
                 TravState ts;
                 trav_begin(ts, ps.o, ps.d, stk, P.sc.wide_root);
-                trav_run_wide<COUNT, false, ALG == 3, STK>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
+                trav_run_wide<COUNT, false, ALG == 3>(ts, P.sc, ps.o, ps.d, cull, stk, tc, 0, 0);
                 h = ts.h;
             } else if (ALG == 1) {
                 TravState ts;
@@ -185,7 +185,7 @@ __device__ __forceinline__ v3 pt_get_sample(const KParams& P, int px, int py, ui
                 TravState ts;
                 if (ALG >= 2) {
                     trav_begin(ts, req.o, req.d, stk, P.sc.wide_root);
-                    trav_run_wide<COUNT, false, ALG == 3, STK>(ts, P.sc, req.o, req.d, cull, stk, tc, 0, 0);
+                    trav_run_wide<COUNT, false, ALG == 3>(ts, P.sc, req.o, req.d, cull, stk, tc, 0, 0);
                 } else if (ALG == 1) {
                     trav_begin(ts, req.o, req.d, stk);
                     trav_run_unified<COUNT, false, STK>(ts, P.sc, req.o, req.d, cull, stk, tc, 0, 0);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the bench step's stages for several builds of libptmi (tools/build_variant.sh), each in a child
-process (PT_LIBPTMI selects the library), interleaved over rounds.  Usage: ab_variants.py tag1 tag2 ... [--kernel 5]"""
+process (PT_LIBPTMI selects the library), interleaved over rounds.  Usage: [PT_AB_REBUILD=2] ab_variants.py tag1 tag2 ... [--kernel 5]"""
 import json
 import os
 import subprocess
@@ -12,7 +12,7 @@ import sys, os, json
 sys.path[:0] = [%r, os.path.join(%r, "tests")]
 import gpu_pathtracer_amd as g
 W, H, spp = 1920, 1080, 16
-pt = g.PathTracer(0); pt.set_option(g.OPT_KERNEL, int(sys.argv[1]))
+pt = g.PathTracer(0); pt.set_option(g.OPT_KERNEL, int(sys.argv[1])); pt.set_option(g.OPT_REBUILD, int(os.environ.get("PT_AB_REBUILD", "0")))
 pt.upload_bvh(g.Bvh(g.scene_mesh("cornell_dragon_800k"))); pt.upload_spheres(g.reference_spheres())
 cam = g.default_camera(W, H); acc, rgba = pt.alloc_frame(W, H)
 pt.set_option(g.OPT_TIMING, 1)
