@@ -560,7 +560,9 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, con
     for (int k = 0; k < cnt; k++) {
         int fp;
         if (ptb_child_is_leaf(B, ref[k], fp)) {
-            link[k] = ~(rec_base + 4 * fp);
+            // a wide node's leaf link also says how many records the leaf holds (low two bits: min(count, 4) - 1)
+            const int n_rec = ref[k] < 0 ? 1 : B.last[ref[k]] - B.first[ref[k]] + 1;
+            link[k] = ~((rec_base + 4 * fp) | (min(n_rec, 4) - 1));
         } else {
             const int slot = (int)atomicAdd(&B.stats[0], 1u);
             link[k] = wide_base + 4 * slot;

@@ -17,7 +17,8 @@
 //           e1 = v1-v0, e2 = v2-v0 (cudaUtils.h:177-178) and the normal (:432) hoisted to upload
 //           with the kernels' own arithmetic; the id rides in v0.w (replaces the gpuTriIndices
 //           remap :452-456), `last` replaces the 0x80000000 terminator fetch (:410-413)
-//   wide  : f4[0] = origin.xyz, bits(ex | ey<<8 | ez<<16 | n_children<<24)
+//   wide  : (a leaf link = ~(float4 index of the first record | min(records, 4) - 1): record indices are multiples of 4)
+//           f4[0] = origin.xyz, bits(ex | ey<<8 | ez<<16 | n_children<<24)
 //           f4[1] = qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4]   (one byte per child per dword)
 //           f4[2] = qhi.y[4], qhi.z[4], link0, link1          f4[3] = link2, link3, 0, 0
 //           child box = origin + q * 2^(e-127), rounded OUTWARD
@@ -375,8 +376,13 @@ inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false) 
             float* d = &out.wide[16 * oi];
             int32_t link[4] = {0, 0, 0, 0};
             for (int k = 0; k < w.n; k++)
-                link[k] = w.child[k] >= 0 ? (int32_t)(wide_base + 4 * pos[(size_t)w.child[k]])
-                                          : ~(int32_t)(rec_base + (size_t)leaf_first[~(int32_t)w.child[k]]);
+                if (w.child[k] >= 0) {
+                    link[k] = (int32_t)(wide_base + 4 * pos[(size_t)w.child[k]]);
+                } else {   // a leaf link also says how many records the leaf holds (low two bits: min(count, 4) - 1)
+                    const size_t li = (size_t)~(int32_t)w.child[k];
+                    const uint32_t n_rec = std::max<uint32_t>(T.leaves[li].count, 1u);   // an empty leaf holds one dummy record
+                    link[k] = ~(int32_t)((rec_base + (size_t)leaf_first[li]) | (size_t)(std::min<uint32_t>(n_rec, 4u) - 1u));
+                }
             PtBox cb[4];
             for (int k = 0; k < w.n; k++)
                 for (int a = 0; a < 3; a++) { cb[k].lo[a] = w.cb[k].lo[a]; cb[k].hi[a] = w.cb[k].hi[a]; }

@@ -368,7 +368,8 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             else { tc.it_rec++; tc.act_rec += n_live - n_node; }
         }
         if (!live || is_node != node_phase) continue;
-        const int a = cur >= 0 ? cur : ~cur;
+        // a leaf link = ~(record index | records - 1 (capped at 3)): wide nodes only (pt_scene_build.h)
+        const int a = cur >= 0 ? cur : (~cur & ~3);
         if (cur >= 0) {
             const WideNode w = wide_node_load(sc, a);
             if (COUNT) tc.inner++;
@@ -413,14 +414,15 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             if (COUNT && cur < 0) tc.leaves++;
         } else {
             float4 q0, q1, q2;
-            // Two thirds of the leaves hold two records (PT_OPT_LEAF_MAX 2): the second one is requested TOGETHER with the
-            // first instead of after its test — one dependent round trip less per such leaf, three wasted 16-byte loads
-            // on a one-record leaf (whatever follows it in the item buffer is read and ignored; the records are never
-            // the buffer's last items).  Extend stage -1.5 % on the uploaded tree, -1.2 % on the re-clustered one.
+            // Two thirds of the leaves hold two records (PT_OPT_LEAF_MAX 2), and the link says so: the second one is
+            // requested TOGETHER with the first instead of after its test — one dependent round trip less per such leaf.
+            // Extend stage -1.5 % on the uploaded tree, -1.2 % on the re-clustered one.
             float4 x0, x1, x2;
             if (!WOOP && AHEAD) {
                 const float4* p_ = sc.nodes + a;
-                q0 = p_[0]; q1 = p_[1]; q2 = p_[2]; x0 = p_[4]; x1 = p_[5]; x2 = p_[6];
+                q0 = p_[0]; q1 = p_[1]; q2 = p_[2];
+                x0 = x1 = x2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((~cur & 3) != 0) { x0 = p_[4]; x1 = p_[5]; x2 = p_[6]; }
                 asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
                                   "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w),
                                   "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w));
@@ -540,7 +542,7 @@ __device__ __forceinline__ bool trav_run_wide_pend(TravState& s, const KScene& s
             }
         } else {
             if (!has_rec) continue;
-            const int a = ~pend;
+            const int a = ~pend & ~3;
             float4 q0, q1, q2;
             pt_ld4x3(sc.nodes + a, q0, q1, q2);
             if (COUNT) tc.tris++;

@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(256) k_tree_cost(const float4* __restrict__ it
                 inner += area;
             } else {
                 int n = 0;
-                for (size_t r = (size_t)(~link[k]);; r += 4) {
+                for (size_t r = (size_t)(~link[k] & ~3);; r += 4) {
                     n++;
                     if (__float_as_int(items[r + 1].w) != 0 || n >= 64) break;   // the record's `last` flag
                 }
