@@ -20,6 +20,7 @@ W, H = 1920, 1080
 SPP = int(os.environ.get("SPP", "16"))
 bvh = g.Bvh(g.scene_mesh("cornell_dragon_800k"))
 pt = g.PathTracer(0)
+pt.set_option(g.OPT_REBUILD, 2)     # as bench.py uploads: keep the tree with fewer node visits
 pt.upload_bvh(bvh)
 pt.upload_spheres(g.reference_spheres())
 cam = g.default_camera(W, H)
