@@ -325,7 +325,8 @@ __device__ __forceinline__ float ptb_area(const float* b) {
 // each other merge into a new inner node; the survivors are compacted in order.  Boxes are known at
 // merge time (no fit pass); node numbers are handed out from the top down so that the last merge —
 // the root — is node 0, where the walks expect it.  Subtrees are no longer contiguous in Morton
-// order, so every triangle is its own leaf (the cut rule is switched off: leaf_max 0).
+// order: the leaves are re-numbered depth-first afterwards (k_ploc_size / k_ploc_first / k_ploc_reorder), which makes
+// every subtree a contiguous record range again, so the cut rule (PT_OPT_LEAF_MAX) applies as in the LBVH.
 #ifndef PTB_PLOC_RADIUS
 #define PTB_PLOC_RADIUS 8
 #endif

@@ -289,7 +289,7 @@ __device__ __forceinline__ void pt_ld4x3(const float4* __restrict__ p, float4& q
 struct WideNode {
     float ox, oy, oz, sx, sy, sz;            // origin, grid step per axis
     uint32_t qlx, qly, qlz, qhx, qhy, qhz;   // lo / hi planes, child k in byte k
-    int l0, l1, l2, l3;                      // links: >= 0 float4 index of a node, < 0 ~(float4 index of a leaf's first record)
+    int l0, l1, l2, l3;                      // links: >= 0 float4 index of a node, < 0 ~(float4 index of a leaf's first record | min(records, 4) - 1)
 };
 
 __device__ __forceinline__ WideNode wide_node_load(const KScene& sc, int a) {
