@@ -33,6 +33,7 @@ if a.scene == "dragon":
 def make(kernel):
     pt = g.PathTracer(0)
     pt.set_option(g.OPT_KERNEL, kernel)
+    pt.set_option(g.OPT_REBUILD, 2)     # as bench.py uploads
     pt.upload_bvh(bvh)
     pt.upload_spheres(sph)
     return pt
@@ -75,7 +76,7 @@ if "knobs" in a.what:
     print(f"{a.scene} {W}x{H} spp {a.spp}: persistent {timed(pp, a.spp, acc2, rgba2):.3f} ms/step")
     for lstk in (16, 24) if "stack" in a.what else ():
         pw.set_option(g.OPT_LDS_STACK, lstk)
-        for batch in (8, 16, 24, 32, 48):
+        for batch in (8, 12, 16, 20, 24, 32, 48):
             pw.set_option(g.OPT_WAVE_BATCH, batch)
             print(f"  wavefront lds_stack {lstk} batch {batch:2d}: {timed(pw, a.spp, acc, rgba):7.3f} ms/step  {stages(pw, a.spp, acc, rgba)}")
     pw.set_option(g.OPT_LDS_STACK, 16)
