@@ -33,6 +33,7 @@ for name, scene, W, H, spp, mat, spheres in CONFIGS:
     for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT)):
         pt = g.PathTracer(0)
         pt.set_option(g.OPT_KERNEL, kern)
+        pt.set_option(g.OPT_REBUILD, 2)      # as bench.py uploads: keep the tree with fewer node visits
         pt.upload_bvh(bvh)
         pt.upload_spheres(g.reference_spheres() if spheres else None)
         cam = g.default_camera(W, H)
