@@ -30,6 +30,10 @@ struct pt_ctx {
     int32_t* d_light_slot = nullptr;
     float4* d_tri_lights = nullptr;
     uint64_t mat_gen = 0, lights_key = ~0ull;
+    // the light list is (re)written on the caller's stream; a side stream (PT_OPT_OVERLAP) waits for lights_ev before its
+    // first kernel that may read that generation of the list
+    hipEvent_t lights_ev = nullptr;
+    uint64_t lights_gen = 0;
     int32_t max_tri_id = -1;           // largest original triangle id of the uploaded BVH
     int n_spheres = 0;
     pt_sphere_d h_spheres[PT_KSPHERES];   // host copy of the first spheres for the kernel-argument block
@@ -72,14 +76,21 @@ struct pt_ctx {
     int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
     // PT_KERNEL_AUTO: which stage layout is faster depends on the workload (long paths and many samples per call:
     // the stage-split pipeline; short paths or few samples: the persistent kernel), so the first two calls of a
-    // configuration time one each (HIP events on the stream) and the following ones run the faster
+    // configuration time one each (HIP events on the stream, buffers allocated before the timed span) and the following
+    // ones run the faster.  A small table of configurations (least recently used replaced): a context that cycles through
+    // a few configurations — the partitions of a tile split, two image sizes — keeps every decision.
     struct AutoPick {
-        uint64_t key = 0;        // what the choice was made for: image, spp, depth, partition, scene generation
-        int phase = 0;           // 0: time the persistent kernel  1: time the pipeline  2: read the events  3: decided
+        uint64_t key = 0;        // what the choice was made for: image, spp, depth, partition shape, scene generation, material, flags
+        int phase = 0;           // 0: time the persistent kernel  1: time the pipeline  2: events pending  3: decided
         int choice = PT_KERNEL_PERSISTENT;
         hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
         float ms[2] = {0.f, 0.f};
-    } pick;
+        uint64_t used = 0;       // tick of the last pt_render that looked this entry up
+    };
+    static constexpr int N_PICKS = 8;
+    AutoPick picks[N_PICKS];
+    int pick_last = -1;          // entry of the last PT_KERNEL_AUTO call (pt_auto_choice), -1 = none
+    uint64_t pick_tick = 0;
     uint64_t scene_gen = 0;      // bumped by every upload / build
     // Overlap of consecutive calls (PT_OPT_OVERLAP, persistent / mega kernels): the path kernel of call k + 1 runs on
     // a side stream into its own sample buffer while call k's last paths drain; only the folds (which touch the
@@ -92,6 +103,7 @@ struct pt_ctx {
         float* samples = nullptr;
         size_t samples_bytes = 0;
         unsigned int* queue = nullptr;
+        uint64_t lights_seen = 0;   // the light list generation this stream has been ordered behind (lights_gen)
     } side[2];
     int side_next = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -154,6 +166,7 @@ hipError_t launch_persist(const LaunchCfg& L, const KParams& P, hipStream_t st);
 hipError_t launch_fold(const KParams& P, hipStream_t st);                            // pt_k_persist.hip
 // stage-split pipeline (pt_k_wave.hip): generate -> depth x (extend, shade) ; returns PT_* status
 int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles);
+int wave_reserve(pt_ctx* c, const KParams& P, int work_tiles);   // path records for this call, allocated now
 // PT_OPT_TIMING: marks the end of a stage of the running call on the context's stream (no-op when timing is off)
 int stage_mark(pt_ctx* c, int kind_of_work_since_last_mark);
 // device BVH builder (pt_build.hip)

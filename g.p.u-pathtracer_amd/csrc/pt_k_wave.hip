@@ -341,29 +341,67 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_resolve(const KParams P) {
 
 namespace ptmi {
 
-int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) {
-    // limits of the record's packed fields: 12 bits of RNG draw count (<= 5 draws per bounce + 2), 20 bits of sample
-    if ((uint64_t)P.depth * 5u + 2u >= 4096u || P.spp >= (1u << 20))
-        return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_KERNEL_WAVEFRONT packs <= 818 bounces and < 2^20 samples per call into a path record");
-    const size_t n_regions = ((size_t)work_tiles + PT_REGION / 64 - 1) / (PT_REGION / 64);
-    const size_t cap = n_regions * PT_REGION;
-    if (cap >= (1ull << 31)) return fail(c, PT_ERR_INVALID, "pt_render: too many path records for one call");
-    // carve: [ray0 x2][ray1 x2][mask x2 (3 planes)][hit][cnt x2][hashes][queues]
-    const size_t b_ray = cap * 16, b_mask = cap * 12, b_hit = cap * 8, b_cnt = ((n_regions * 4 + 255) / 256) * 256;
-    const size_t b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
-    const bool nee = (P.flags & PT_FLAG_NEE) != 0;
-    if (nee && P.spp >= (1u << 19)) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_FLAG_NEE in the stage-split pipeline packs < 2^19 samples per call into a path record");
-    const size_t q_words = (size_t)P.depth * (nee ? 2 : 1) * PT_SHARDS * PT_SHARD_STRIDE, b_q = q_words * 4;
-    const size_t b_nee = nee ? 3 * b_ray + b_hit + b_cnt : 0;   // shadow records: s_ray0, s_ray1, s_con, s_hit, s_cnt
-    const size_t need = 4 * b_ray + 2 * b_mask + b_hit + 2 * b_cnt + b_hash + b_q + b_nee;
-    if (need > c->wave_bytes) {
+// sizes of one call's path records: [ray0 x2][ray1 x2][mask x2 (3 planes)][hit][cnt x2][hashes][queues][shadow records]
+struct WaveLayout {
+    size_t n_regions, cap, b_ray, b_mask, b_hit, b_cnt, b_hash, q_words, b_q, b_nee, need;
+    bool nee;
+};
+
+// most RNG draws one bounce can make with these flags (path_shade_hit): DIFF 4, or 2 cosine-weighted (+ 3 for the light
+// sample of PT_FLAG_NEE), METAL 2, REFR 1, + 1 per roulette switch
+static uint32_t draws_per_bounce(uint32_t flags) {
+    uint32_t k = (flags & PT_FLAG_COSINE_DIFF) ? 2u : 4u;
+    if (flags & PT_FLAG_NEE) k += 3u;
+    if (flags & PT_FLAG_RUSSIAN_ROULETTE) k += 1u;
+    if (flags & PT_FLAG_RR_CPU_TRACER) k += 1u;
+    return k;
+}
+
+static int wave_layout(pt_ctx* c, const KParams& P, int work_tiles, WaveLayout& w) {
+    // limits of the record's packed fields: 12 bits of RNG draw count (2 camera draws + draws_per_bounce per bounce), 20 bits of sample
+    if ((uint64_t)P.depth * draws_per_bounce(P.flags) + 2u >= 4096u || P.spp >= (1u << 20))
+        return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_KERNEL_WAVEFRONT packs < 4096 RNG draws per path (2 + depth x 4..9, by flags) and < 2^20 samples per call into a path record");
+    w.n_regions = ((size_t)work_tiles + PT_REGION / 64 - 1) / (PT_REGION / 64);
+    w.cap = w.n_regions * PT_REGION;
+    if (w.cap >= (1ull << 31)) return fail(c, PT_ERR_INVALID, "pt_render: too many path records for one call");
+    w.b_ray = w.cap * 16; w.b_mask = w.cap * 12; w.b_hit = w.cap * 8; w.b_cnt = ((w.n_regions * 4 + 255) / 256) * 256;
+    w.b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
+    w.nee = (P.flags & PT_FLAG_NEE) != 0;
+    if (w.nee && P.spp >= (1u << 19)) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_FLAG_NEE in the stage-split pipeline packs < 2^19 samples per call into a path record");
+    w.q_words = (size_t)P.depth * (w.nee ? 2 : 1) * PT_SHARDS * PT_SHARD_STRIDE;
+    w.b_q = w.q_words * 4;
+    w.b_nee = w.nee ? 3 * w.b_ray + w.b_hit + w.b_cnt : 0;   // shadow records: s_ray0, s_ray1, s_con, s_hit, s_cnt
+    w.need = 4 * w.b_ray + 2 * w.b_mask + w.b_hit + 2 * w.b_cnt + w.b_hash + w.b_q + w.b_nee;
+    return PT_OK;
+}
+
+// makes sure the context holds path records for this call (PT_KERNEL_AUTO calls it ahead of the timed span of its trial)
+int wave_reserve(pt_ctx* c, const KParams& P, int work_tiles) {
+    WaveLayout w;
+    const int rc = wave_layout(c, P, work_tiles, w);
+    if (rc != PT_OK) return rc;
+    if (w.need > c->wave_bytes) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_wave);
         c->d_wave = nullptr;
         c->wave_bytes = 0;
-        HIP_TRY(c, hipMalloc(&c->d_wave, need));
-        c->wave_bytes = need;
+        HIP_TRY(c, hipMalloc(&c->d_wave, w.need));
+        c->wave_bytes = w.need;
     }
+    return PT_OK;
+}
+
+int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) {
+    WaveLayout w;
+    {
+        const int rc = wave_layout(c, P, work_tiles, w);
+        if (rc != PT_OK) return rc;
+        const int rc2 = wave_reserve(c, P, work_tiles);
+        if (rc2 != PT_OK) return rc2;
+    }
+    const size_t n_regions = w.n_regions, cap = w.cap, b_ray = w.b_ray, b_mask = w.b_mask, b_hit = w.b_hit, b_cnt = w.b_cnt, b_hash = w.b_hash;
+    const size_t q_words = w.q_words, b_q = w.b_q;
+    const bool nee = w.nee;
     char* base = (char*)c->d_wave;
     float4* ray0[2] = {(float4*)base, (float4*)(base + b_ray)};
     float4* ray1[2] = {(float4*)(base + 2 * b_ray), (float4*)(base + 3 * b_ray)};

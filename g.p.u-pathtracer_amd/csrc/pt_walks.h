@@ -20,6 +20,12 @@
 // One extern array so the carve base stays 16-byte aligned (cdna guide G17).
 extern __shared__ float4 s_dyn[];
 
+// Sensitivity experiments (tools/pt_exp_hooks.h, built only by tools/build_variant.sh) splice code into the wide walk's
+// node step through this hook; the product build leaves it empty.
+#ifndef PT_NODE_STEP_HOOK
+#define PT_NODE_STEP_HOOK(sc, a, w)
+#endif
+
 struct TravState {
     float idx, idy, idz, oodx, oody, oodz;
     int node, leaf, sp;
@@ -373,29 +379,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         if (cur >= 0) {
             const WideNode w = wide_node_load(sc, a);
             if (COUNT) tc.inner++;
-#ifdef PT_EXP_LOAD   // sensitivity experiment: one more 16-byte access to the node's line per node step
-            { float4 dummy; const float4* ptr_ = sc.nodes + a + 2;   // a real second access to the same line (not CSE'd)
-              asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(dummy) : "v"(ptr_) : "memory");
-              asm volatile("" :: "v"(dummy.x), "v"(dummy.w)); }
-#endif
-#ifdef PT_EXP_SALU   // sensitivity experiment: 32 more dependent scalar instructions per node step
-            { int z = 1;
-#pragma unroll
-              for (int e = 0; e < 32; e++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(z) :: "scc");
-              asm volatile("" :: "s"(z)); }
-#endif
-#ifdef PT_EXP_BRANCH   // sensitivity experiment: 8 more (never taken) exec-mask branch pairs per node step
-            { int zb = w.l0;
-#pragma unroll
-              for (int e = 0; e < 8; e++) { if (zb == 0x7fffff01 + e) { asm volatile("v_mov_b32 %0, 0" : "+v"(zb)); } asm volatile("" : "+v"(zb)); }
-              asm volatile("" :: "v"(zb)); }
-#endif
-#ifdef PT_EXP_VALU   // sensitivity experiment: 32 more dependent VALU instructions per node step
-            { float z = w.ox;
-#pragma unroll
-              for (int e = 0; e < 32; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(z));
-              asm volatile("" :: "v"(z)); }
-#endif
+            PT_NODE_STEP_HOOK(sc, a, w);
             uint32_t key[4];
             wide_node_keys(w, idx, idy, idz, oodx, oody, oodz, h.t, key);
             if (key[3] != 0xffffffffu) { sp++; stk.put(sp, wide_link(w, key[3])); }

@@ -19,20 +19,8 @@ static_assert(sizeof(pt_sphere) == 44, "pt_sphere must match the reference Spher
 static_assert(sizeof(pt_sphere_d) == sizeof(pt_sphere), "device sphere mirror");
 static_assert(sizeof(pt_params) == 104 && sizeof(pt_camera) == 64 && sizeof(pt_counters) == 48, "ABI struct sizes (tests/test_host_and_abi.py)");
 
-#include <execinfo.h>
-#include <signal.h>
-#include <unistd.h>
 namespace ptmi {
 thread_local std::string g_err;
-static void dbg_segv(int sig) {
-    void* bt[64];
-    const int n = backtrace(bt, 64);
-    const char msg[] = "ptmi debug: fatal signal, native backtrace:\n";
-    (void)!write(2, msg, sizeof msg - 1);
-    backtrace_symbols_fd(bt, n, 2);
-    signal(sig, SIG_DFL);
-    raise(sig);
-}
 }
 using namespace ptmi;
 
@@ -97,7 +85,6 @@ int pt_create(int device, pt_ctx** out) {
     if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceCount");
     if (device < 0 || device >= n) return fail(nullptr, PT_ERR_INVALID, "pt_create: no such device");
     pt_ctx* c = new pt_ctx();
-    if (getenv("PT_DEBUG_SEGV")) signal(SIGSEGV, ptmi::dbg_segv);
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipSetDevice"); }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
@@ -136,7 +123,9 @@ int pt_destroy(pt_ctx* c) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     for (hipEvent_t e : c->stage_ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->pick.e) if (e) (void)hipEventDestroy(e);
+    for (pt_ctx::AutoPick& a : c->picks)
+        for (hipEvent_t e : a.e) if (e) (void)hipEventDestroy(e);
+    if (c->lights_ev) (void)hipEventDestroy(c->lights_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -543,6 +532,10 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
                                c->d_light_slot, (uint32_t)c->n_tri_matid, c->d_tri_matid, c->d_mat_table, c->d_tri_lights);
             HIP_TRY(c, hipGetLastError());
             c->lights_key = key;
+            // a path kernel on a side stream (PT_OPT_OVERLAP) must not read the list before it is written
+            if (!c->lights_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->lights_ev, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->lights_ev, c->stream));
+            c->lights_gen++;
         }
         P.tri_lights = c->d_tri_lights;
         P.n_tri_lights = (int)c->emissive_ids.size();
@@ -576,27 +569,48 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     const bool wave_ok = c->has_bvh && P.depth > 0 && walk == 2;
     int kernel = c->opt_kernel;
     int probe = -1;   // PT_KERNEL_AUTO: 0 / 1 = this call is the timed trial of the persistent kernel / the pipeline
+    pt_ctx::AutoPick* pick = nullptr;
     if (kernel == PT_KERNEL_AUTO) {
         kernel = PT_KERNEL_PERSISTENT;
         if (wave_ok && !c->opt_counters && !(p->flags & PT_FLAG_NEE)) {
-            pt_ctx::AutoPick& a = c->pick;
+            // the key holds the SHAPE of the partition, not which part this call renders: the parts of a tile split cost alike
             uint64_t key = 0xcbf29ce484222325ull;
-            const uint64_t parts[] = {(uint64_t)p->width, (uint64_t)p->height, (uint64_t)spp, (uint64_t)p->depth, (uint64_t)p->part_index,
-                                      (uint64_t)p->part_count, (uint64_t)p->part_rows, c->scene_gen, (uint64_t)c->n_spheres,
-                                      (uint64_t)p->tri_mat, (uint64_t)(p->flags & ~(uint32_t)PT_FLAG_WRITE_RGBA)};
+            const uint64_t parts[] = {(uint64_t)p->width, (uint64_t)p->height, (uint64_t)spp, (uint64_t)p->depth,
+                                      (uint64_t)(p->part_count > 1 ? p->part_count : 1), (uint64_t)(p->part_count > 1 ? p->part_rows : 0), c->scene_gen,
+                                      (uint64_t)c->n_spheres, (uint64_t)p->tri_mat, (uint64_t)(p->flags & ~(uint32_t)PT_FLAG_WRITE_RGBA)};
             for (uint64_t v : parts) { key ^= v; key *= 0x100000001b3ull; }
-            if (key != a.key) { a.key = key; a.phase = 0; }
-            if (a.phase == 2) {   // both trials are queued or done: read their times (waits for them if need be)
-                bool ok = true;
-                for (int t = 0; t < 2 && ok; t++)
-                    ok = hipEventSynchronize(a.e[2 * t + 1]) == hipSuccess && hipEventElapsedTime(&a.ms[t], a.e[2 * t], a.e[2 * t + 1]) == hipSuccess;
-                a.choice = ok && a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;
-                a.phase = 3;
-                if (a.choice == PT_KERNEL_PERSISTENT && c->d_wave) {   // the pipeline's path records are not needed
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    (void)hipFree(c->d_wave);
-                    c->d_wave = nullptr;
-                    c->wave_bytes = 0;
+            if (key == 0) key = 1;
+            int slot = -1, lru = 0;
+            for (int i = 0; i < pt_ctx::N_PICKS; i++) {
+                if (c->picks[i].key == key) { slot = i; break; }
+                if (c->picks[i].used < c->picks[lru].used) lru = i;
+            }
+            if (slot < 0) {
+                slot = lru;
+                pt_ctx::AutoPick& n = c->picks[slot];
+                if (n.phase == 1 || n.phase == 2)   // a trial of the configuration it held may still be in flight: its events must be idle
+                    for (hipEvent_t e : n.e) if (e) (void)hipEventSynchronize(e);
+                n.key = key; n.phase = 0; n.choice = PT_KERNEL_PERSISTENT; n.ms[0] = n.ms[1] = 0.f;
+            }
+            pt_ctx::AutoPick& a = c->picks[slot];
+            a.used = ++c->pick_tick;
+            c->pick_last = slot;
+            pick = &a;
+            if (a.phase == 2) {   // both trials are queued: decide once their events have completed, never wait for them
+                if (hipEventQuery(a.e[3]) == hipSuccess && hipEventQuery(a.e[1]) == hipSuccess) {
+                    const bool ok = hipEventElapsedTime(&a.ms[0], a.e[0], a.e[1]) == hipSuccess && hipEventElapsedTime(&a.ms[1], a.e[2], a.e[3]) == hipSuccess;
+                    a.choice = ok && a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;
+                    a.phase = 3;
+                    bool wave_wanted = false;   // by any remembered configuration
+                    for (const pt_ctx::AutoPick& o : c->picks)
+                        if (o.key && (o.phase == 1 || o.phase == 2 || (o.phase == 3 && o.choice == PT_KERNEL_WAVEFRONT))) wave_wanted = true;
+                    if (!wave_wanted && c->d_wave) {   // the pipeline's path records (3 GB at 1080p x 16 spp) are not needed; the trial that used them is done
+                        (void)hipFree(c->d_wave);
+                        c->d_wave = nullptr;
+                        c->wave_bytes = 0;
+                    }
+                } else {
+                    (void)hipGetLastError();   // hipErrorNotReady is not an error of this call
                 }
             }
             if (a.phase < 2) {
@@ -606,7 +620,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
                 kernel = probe == 0 ? PT_KERNEL_PERSISTENT : PT_KERNEL_WAVEFRONT;
                 a.phase++;
             } else {
-                kernel = a.choice;
+                kernel = a.phase == 3 ? a.choice : PT_KERNEL_PERSISTENT;
             }
         }
     }
@@ -665,10 +679,18 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (sd) {
         trace_stream = sd->stream;
         if (sd->fold_pending) HIP_TRY(c, hipStreamWaitEvent(sd->stream, sd->folded, 0));
+        if (P.tri_lights && sd->lights_seen != c->lights_gen) {   // the light list was (re)written on the caller's stream
+            HIP_TRY(c, hipStreamWaitEvent(sd->stream, c->lights_ev, 0));
+            sd->lights_seen = c->lights_gen;
+        }
     }
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe], c->stream));
+    if (probe == 1) {   // the pipeline's trial: its path records are allocated BEFORE the timed span
+        const int rc = wave_reserve(c, P, work_tiles);
+        if (rc != PT_OK) return rc;
+    }
+    if (probe >= 0) HIP_TRY(c, hipEventRecord(pick->e[2 * probe], c->stream));
     if (c->opt_timing) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         c->stage_used = 0;
@@ -738,7 +760,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
         HIP_TRY(c, hipEventRecord(sd->folded, c->stream));
         sd->fold_pending = true;
     }
-    if (probe >= 0) HIP_TRY(c, hipEventRecord(c->pick.e[2 * probe + 1], c->stream));
+    if (probe >= 0) HIP_TRY(c, hipEventRecord(pick->e[2 * probe + 1], c->stream));
     if (c->opt_timing) { HIP_TRY(c, hipEventRecord(c->ev1, c->stream)); c->timed = true; }
     return PT_OK;
 }
@@ -827,9 +849,19 @@ int pt_tree_cost(pt_ctx* c, double* node_visits, double* tri_tests) {
 
 int pt_auto_choice(pt_ctx* c, int* kernel, float* ms_persistent, float* ms_wavefront) {
     if (!c || !kernel) return fail(c, PT_ERR_INVALID, "pt_auto_choice: null argument");
-    *kernel = c->pick.phase >= 3 ? c->pick.choice : PT_KERNEL_AUTO;
-    if (ms_persistent) *ms_persistent = c->pick.ms[0];
-    if (ms_wavefront) *ms_wavefront = c->pick.ms[1];
+    *kernel = PT_KERNEL_AUTO;
+    if (ms_persistent) *ms_persistent = 0.f;
+    if (ms_wavefront) *ms_wavefront = 0.f;
+    if (c->pick_last < 0) return PT_OK;
+    pt_ctx::AutoPick& a = c->picks[c->pick_last];
+    if (a.phase == 2 && hipEventSynchronize(a.e[1]) == hipSuccess && hipEventSynchronize(a.e[3]) == hipSuccess &&
+        hipEventElapsedTime(&a.ms[0], a.e[0], a.e[1]) == hipSuccess && hipEventElapsedTime(&a.ms[1], a.e[2], a.e[3]) == hipSuccess) {
+        a.choice = a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;   // the caller asks: waiting is fine here
+        a.phase = 3;
+    }
+    if (a.phase >= 3) *kernel = a.choice;
+    if (ms_persistent) *ms_persistent = a.ms[0];
+    if (ms_wavefront) *ms_wavefront = a.ms[1];
     return PT_OK;
 }
 

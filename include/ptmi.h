@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PTMI_ABI_VERSION 2
+#define PTMI_ABI_VERSION 3
 
 typedef struct pt_ctx pt_ctx;
 
@@ -106,25 +106,24 @@ enum {
 /* ... and with that renderer's own roulette instead of the unbiased one: its images, bias included */
 #define PT_FLAGS_CPU_TRACER (PT_FLAG_FACE_FORWARD | PT_FLAG_COSINE_DIFF | PT_FLAG_RR_CPU_TRACER | PT_FLAG_MISS_KEEPS_PATH)
 
-/* pt_ctx kernel selection (pt_set_option PT_OPT_KERNEL) */
+/* pt_ctx kernel selection (pt_set_option PT_OPT_KERNEL).  The values 2 and 4 of ABI 1-2 (a reserved name and the
+ * round-1 role-split experiment) are gone with ABI 3: pt_set_option rejects them with PT_ERR_UNSUPPORTED. */
 enum {
     PT_KERNEL_AUTO = 0,      /* PT_KERNEL_PERSISTENT or PT_KERNEL_WAVEFRONT, whichever is faster for the
-                                configuration (image, samples per call, depth, partition, scene): its first
-                                two pt_render calls time one each with HIP events and the following ones
-                                run the faster (the images are the same); pt_auto_choice reports it    */
+                                configuration (image, samples per call, depth, partition shape, scene, material,
+                                flags): the first two pt_render calls of a configuration time one layout each
+                                with HIP events (buffers are allocated before the timed span) and the following
+                                ones run the faster; the images are the same.  The decision never blocks the
+                                host: while a trial's events are still pending, calls run the persistent kernel.
+                                The library remembers the last 8 configurations.  pt_auto_choice reports it   */
     PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, one wave per 8x8 tile, bounce by bounce      */
-    PT_KERNEL_MEGA_WIDE = 2, /* reserved: wide compressed nodes (not in this build)              */
     PT_KERNEL_PERSISTENT = 3,/* persistent waves: work queue, ballot/prefix-count lane refill    */
-    PT_KERNEL_ROLE_SPLIT = 4,/* removed in ABI 2 (round-1 experiment: tracer / shader waves inside a
-                                block; never ahead of PT_KERNEL_PERSISTENT); rejected
-                                with PT_ERR_UNSUPPORTED                                          */
     PT_KERNEL_WAVEFRONT = 5  /* stage split (BASELINE.json configs[4]): path records in HBM, one
-                                launch per stage — generate, then per bounce extend (persistent
-                                waves walking the BVH, lanes refilled from the ray queue) and shade
-                                (one lane per live path; survivors compacted with a ballot /
-                                prefix count into the next generation).  Needs a BVH, depth >= 1
-                                and the wide walk over exact records; anything else runs
-                                PT_KERNEL_PERSISTENT.  Same images                                */
+                                launch per stage — per bounce extend (persistent waves walking the
+                                BVH, lanes refilled from the ray queue) and shade (one lane per
+                                live path; survivors compacted with a ballot / prefix count into
+                                the next generation).  Needs a BVH, depth >= 1 and the wide walk
+                                over exact records; anything else runs PT_KERNEL_PERSISTENT.  Same images */
 };
 
 enum {
@@ -166,8 +165,12 @@ enum {
                                  degenerate input falls back to 0), 0 = LBVH (Karras hierarchy: 1.8 ms, a
                                  tree that traces ~14 % slower)                                    */
     PT_OPT_REBUILD = 17,      /* pt_upload_bvh: 1 = keep the uploaded TRIANGLES but build the hierarchy again on
-                                 the device (PT_OPT_BUILD_ALGO); same images (the closest hit does not depend
-                                 on the tree); faster or slower than the caller's tree depending on the scene.
+                                 the device (PT_OPT_BUILD_ALGO).  Same closest hits, hence the same images, except
+                                 where a ray GRAZES a bounding plane: the binary32 slab test is not watertight, so
+                                 a hit whose box is missed by one rounding in one tree and kept in the other can
+                                 differ (measured: 2 of 2 073 600 pixels of the 16-spp 800k-triangle bench frame;
+                                 every such pixel is arbitrated against brute force in tests/test_gpu_wide.py).
+                                 Faster or slower than the caller's tree depending on the scene.
                                  2 = build it as well and keep whichever 4-wide tree has the smaller area cost
                                  in node visits (pt_tree_cost: the term that tracks the measured frame time,
                                  DESIGN.md 5.5) — the caller's on architectural scenes with long triangles
@@ -283,8 +286,9 @@ int pt_upload_spheres(pt_ctx* ctx, const pt_sphere* spheres, size_t n_spheres);
  * (the reference builds on the host: SplitBVHBuilder.cpp, BasicScene.cpp:281-294).
  * Morton order + PLOC clustering (or the Karras linear BVH, PT_OPT_BUILD_ALGO) collapsed into the
  * same item buffer pt_upload_bvh produces, in milliseconds; the PLOC tree traces as fast as the host
- * SAH/SBVH builder's.  Rendered images are the same bit for bit (the closest hit does not depend
- * on the tree).  Triangle ids are the row numbers of `tris`.  PT_OPT_LEAF_MAX (default 2)
+ * SAH/SBVH builder's.  Rendered images equal those over an uploaded hierarchy except for rays that graze a
+ * bounding plane (see PT_OPT_REBUILD: a handful of pixels per 2 M at 800 k triangles, none on the small
+ * scenes of the test suite).  Triangle ids are the row numbers of `tris`.  PT_OPT_LEAF_MAX (default 2)
  * = triangles per leaf.  verts: float[n_verts][3], tris: int32[n_tris][3]; host arrays, copied. */
 int pt_build_bvh(pt_ctx* ctx, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris);
 int pt_last_build_ms(pt_ctx* ctx, float* ms_out);   /* device time of the build behind the tree on the context (pt_build_bvh or a

@@ -389,6 +389,14 @@ void orc_camera_ray(const pt_camera* cam, int px, int py, int w, int h, float u0
 /* PT_FLAG_NEE over emissive triangles (ptmi.h): the light list the product derives from the material table —
  * every triangle whose row emits, ascending original id, as (v0, emi.r) (e1 = v1 - v0, emi.g) (e2 = v2 - v0, emi.b),
  * binary32 subtraction as at upload.  The tests build it from the mesh and hand it over before a render. */
+/* The ARBITER (orc_sample_pixels): with a raw mesh set, get_sample's closest hit is the brute-force loop over every
+ * triangle instead of the BVH walk, and each segment's (t, triangle) can be logged.  Thread-local: set per worker. */
+static _Thread_local const float* tl_brute_verts = 0;
+static _Thread_local const int32_t* tl_brute_vidx = 0;
+static _Thread_local size_t tl_brute_n = 0;
+static _Thread_local float* tl_seg_log = 0;      /* [cap][2]: t, triangle id (as float bits) per segment */
+static _Thread_local uint32_t tl_seg_cap = 0;
+
 static const float* g_tri_lights = 0;
 static size_t g_n_tri_lights = 0;
 void orc_set_tri_lights(const float* lights12, size_t n) {
@@ -413,8 +421,10 @@ static v3 get_sample(const float* nodes, const float* tris, const int32_t* tidx,
         int geom = 3; /* GeoType::NONE */
         int sph_id = -1;
         hit_t h = {F32_MAX, -1, {0, 0, 0}};
-        if (nodes) h = bvh_intersect(nodes, tris, tidx, o, d, P->cull_backfaces, cnt);
+        if (tl_brute_n) { h = brute_intersect(tl_brute_verts, tl_brute_vidx, tl_brute_n, o, d, P->cull_backfaces); if (cnt) cnt->rays++; }
+        else if (nodes) h = bvh_intersect(nodes, tris, tidx, o, d, P->cull_backfaces, cnt);
         else if (cnt) cnt->rays++;
+        if (tl_seg_log && depth < tl_seg_cap) { tl_seg_log[2 * depth] = h.t; tl_seg_log[2 * depth + 1] = bits2f((uint32_t)h.tri); }
         float scene_t = h.t;
         if (h.tri != -1) geom = 0; /* TRI */
         /* intersectAllSpeheres, cudaUtils.h:221-236 */
@@ -698,6 +708,34 @@ int orc_render_mat(float* accum, uint32_t* rgba,
         }
     }
     if (cnt) *cnt = total;
+    return 0;
+}
+
+/* Selected pixels, sample by sample (the tests' arbiter for pixels where two renders differ): out_col[n][spp][3] = the
+ * sample colours BEFORE the fold, out_seg[n][spp][depth][2] (may be NULL) = every segment's (t, triangle id bits; F32_MAX /
+ * -1 where the path had ended).  Closest hits come from the BVH arrays, or — when nodes is NULL and a raw mesh is given —
+ * from the brute-force loop over all its triangles (no tree: nothing can be culled by a box).  Global material only. */
+int orc_sample_pixels(const float* nodes, const float* tris, const int32_t* tidx,
+                      const float* verts, const int32_t* tri_vidx, size_t n_tris,
+                      const pt_sphere* sph, size_t n_sph, const pt_camera* cam, const pt_params* P, uint32_t spp,
+                      const int32_t* pixels_xy, size_t n, float* out_col, float* out_seg) {
+    if (!cam || !P || !pixels_xy || !out_col || (!nodes && !(verts && tri_vidx && n_tris))) return -1;
+    const long total = (long)n * (long)spp;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long k = 0; k < total; k++) {
+        const size_t i = (size_t)(k / spp);
+        const uint32_t s = (uint32_t)(k % spp);
+        const int x = pixels_xy[2 * i], y = pixels_xy[2 * i + 1];
+        const uint64_t pix = (uint64_t)y * (uint64_t)P->width + (uint64_t)x;
+        float* seg = out_seg ? out_seg + 2 * (size_t)P->depth * (size_t)k : 0;
+        if (seg) for (uint32_t d = 0; d < P->depth; d++) { seg[2 * d] = F32_MAX; seg[2 * d + 1] = bits2f(0xffffffffu); }
+        if (!nodes) { tl_brute_verts = verts; tl_brute_vidx = tri_vidx; tl_brute_n = n_tris; }
+        tl_seg_log = seg; tl_seg_cap = P->depth;
+        rng_t rng = rng_init(P->frame + s, pix);
+        const v3 col = get_sample(nodes, tris, tidx, sph, n_sph, cam, P, NULL, NULL, x, y, &rng, NULL);
+        tl_brute_n = 0; tl_seg_log = 0; tl_seg_cap = 0;
+        out_col[3 * k] = col.x; out_col[3 * k + 1] = col.y; out_col[3 * k + 2] = col.z;
+    }
     return 0;
 }
 

@@ -39,6 +39,10 @@ int orc_render_mat(float* accum, uint32_t* rgba,
 /* PT_FLAG_NEE over emissive triangles: the light list ((v0, emi.r) (e1, emi.g) (e2, emi.b) per triangle whose material row
  * emits, ascending id) used by the following orc_render_mat calls; n = 0 clears it.  Not copied: keep the array alive. */
 void orc_set_tri_lights(const float* lights12, size_t n);
+int orc_sample_pixels(const float* nodes, const float* tris, const int32_t* tidx,
+                      const float* verts, const int32_t* tri_vidx, size_t n_tris,
+                      const pt_sphere* sph, size_t n_sph, const pt_camera* cam, const pt_params* P, uint32_t spp,
+                      const int32_t* pixels_xy, size_t n, float* out_col, float* out_seg);
 void orc_primary_rays(const pt_camera* cam, int W, int H, uint64_t frame, int jitter, float* rays8);
 
 #ifdef __cplusplus

@@ -50,6 +50,9 @@ def lib():
                                      C.POINTER(g.Camera), C.POINTER(g.Params), C.c_uint32, C.POINTER(g.Counters)]
         L.orc_set_tri_lights.restype = None
         L.orc_set_tri_lights.argtypes = [vp, sz]
+        L.orc_sample_pixels.restype = i32
+        L.orc_sample_pixels.argtypes = [vp, vp, vp, vp, vp, sz, C.POINTER(g.Sphere), sz, C.POINTER(g.Camera), C.POINTER(g.Params),
+                                        C.c_uint32, vp, sz, vp, vp]
         L.orc_primary_rays.restype = None
         L.orc_primary_rays.argtypes = [C.POINTER(g.Camera), i32, i32, C.c_uint64, i32, vp]
         _lib = L
@@ -101,6 +104,38 @@ def render(bvh, spheres, cam, params, spp=1, accum=None, want_rgba=True, materia
                               spheres if n_s else None, n_s, C.byref(cam), C.byref(params), spp, C.byref(cnt))
     assert rc == 0
     return accum, rgba, counters_dict(cnt)
+
+
+def sample_pixels(pixels_xy, spheres, cam, params, spp, bvh=None, mesh=None):
+    """Selected pixels sample by sample: the colours before the fold [n][spp][3] and every segment's (t, triangle id)
+    [n][spp][depth].  bvh: hits from the oracle's walk over the Compact arrays; mesh (bvh None): hits from the
+    BRUTE-FORCE loop over the raw triangles — the arbiter for pixels where two renders differ."""
+    px = np.ascontiguousarray(pixels_xy, np.int32).reshape(-1, 2)
+    n, depth = len(px), params.depth
+    col = np.zeros((n, spp, 3), np.float32)
+    seg = np.zeros((n, spp, depth, 2), np.float32)
+    n_s = len(spheres) if spheres is not None else 0
+    if bvh is not None:
+        rc = lib().orc_sample_pixels(bvh.nodes.ctypes.data, bvh.tris.ctypes.data, bvh.index.ctypes.data, None, None, 0,
+                                     spheres if n_s else None, n_s, C.byref(cam), C.byref(params), spp, px.ctypes.data, n,
+                                     col.ctypes.data, seg.ctypes.data)
+    else:
+        v, f = np.ascontiguousarray(mesh.verts), np.ascontiguousarray(mesh.tris)
+        rc = lib().orc_sample_pixels(None, None, None, v.ctypes.data, f.ctypes.data, len(f), spheres if n_s else None, n_s,
+                                     C.byref(cam), C.byref(params), spp, px.ctypes.data, n, col.ctypes.data, seg.ctypes.data)
+    assert rc == 0
+    return col, seg[..., 0], seg[..., 1].view(np.int32)
+
+
+def fold_samples(col, first_n, accum=None):
+    """The running mean of tracer.cu:386-391 over the sample colours col[..., spp, 3], N = first_n, first_n + 1, ..."""
+    col = np.asarray(col, np.float32)
+    acc = np.zeros(col.shape[:-2] + (3,), np.float32) if accum is None else np.array(accum, np.float32)
+    flat_a, flat_c = acc.reshape(-1, 3), col.reshape(-1, col.shape[-2], 3)
+    for i in range(len(flat_a)):
+        for s in range(col.shape[-2]):
+            lib().orc_accumulate(flat_a[i].ctypes.data, None, flat_c[i, s].ctypes.data, first_n + s)
+    return acc
 
 
 def trace_bvh(bvh, rays, cull=True):

@@ -164,7 +164,7 @@ def test_ptmi_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", g._abi.PTMI_PATH]).decode()
     exported = set(re.findall(r" T (pt_[a-z_0-9]+)", out))
     assert declared <= exported
-    assert lib.pt_abi_version() == 2
+    assert lib.pt_abi_version() == 3
 
 
 def test_ptmi_is_gfx950_code_object():

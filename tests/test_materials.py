@@ -365,3 +365,45 @@ def test_gpu_nee_over_emissive_triangles_equals_oracle(pt, scene, spheres):
     assert a.mean() > 0.01
     # without the table the flag falls back to the spheres alone (and to nothing at all without spheres)
     pt.upload_tri_materials(None, None)
+
+
+@pytest.mark.gpu
+def test_gpu_first_nee_call_behind_busy_stream_reads_written_lights():
+    """The light list is rebuilt on the caller's stream by the first PT_FLAG_NEE call after a scene / material change, while
+    the megakernel of that call runs on a side stream (PT_OPT_OVERLAP): it must be ordered behind the rebuild.  Several
+    heavy plain calls are queued first, with no sync, so that the caller's stream is still busy when the NEE call is issued."""
+    mesh = g.scene_mesh("cornell_box_dragon")
+    bvh = g.Bvh(mesh)
+    lights = orc.tri_lights(mesh, mesh.materials, mesh.tri_material)
+    W, H, spp = 200, 150, 2
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.depth, p.frame, p.flags = 5, 7, NEE | g.FLAG_WRITE_RGBA
+    p.bk_color[:] = (0, 0, 0)
+    ref, _, _ = orc.render(bvh, None, cam, p, spp, materials=mesh.materials, tri_material=mesh.tri_material, lights=lights)
+    t = g.PathTracer(0)
+    try:
+        t.set_option(g.OPT_KERNEL, g.KERNEL_MEGA_BVH2)
+        t.set_option(g.OPT_WALK, 1)
+        t.upload_bvh(bvh)
+        t.upload_tri_materials(mesh.materials, mesh.tri_material)
+        acc, rgba = t.alloc_frame(W, H)
+        BW, BH = 1920, 1080
+        big_acc, big_rgba = t.alloc_frame(BW, BH)
+        bcam, bp = g.default_camera(BW, BH), g.default_params(BW, BH)
+        bp.depth = 6
+        for rep in range(3):
+            for k in range(3):                      # plain calls: their folds keep the caller's stream busy
+                bp.frame = 100 + k
+                t.launch_kernel(big_acc.ptr, big_rgba.ptr, bcam, bp, 4)
+            t.upload_tri_materials(mesh.materials, mesh.tri_material)   # new material generation: the next NEE call rebuilds the lights
+            for k in range(3):
+                bp.frame = 200 + k
+                t.launch_kernel(big_acc.ptr, big_rgba.ptr, bcam, bp, 4)
+            acc.zero()
+            t.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)              # no sync in between
+            t.sync()
+            a = acc.download(np.float32, (H, W, 3))
+            assert np.isfinite(a).all()
+            assert np.array_equal(a, ref), int(np.any(a != ref, axis=-1).sum())
+    finally:
+        t.close()

@@ -282,3 +282,21 @@ def test_config1_cornell_256_through_the_reference_cpu_tracer(tmp_path):
     img = np.fromfile(out, np.float32).reshape(256, 256, 3)
     assert j["paths"] == 256 * 256 and j["segments"] >= j["paths"]
     assert np.isfinite(img).all() and 0.05 < img.mean() < 2.2 and abs(img.mean() - j["mean"]) < 1e-4
+
+
+def test_arbiter_sample_pixels_matches_render_and_brute_force():
+    """orc.sample_pixels (the arbiter of the GPU tests' differing pixels): folded sample colours == orc.render's pixels, and the
+    brute-force closest hit (no tree) reproduces the walk's segments on a scene without grazing cases."""
+    mesh = g.scene_mesh("cornell_dragon")
+    bvh = g.Bvh(mesh)
+    W, H, spp = 64, 48, 3
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    cam.dist = 18.0 * H / 1080
+    sph = g.reference_spheres()
+    ref, _, _ = orc.render(bvh, sph, cam, p, spp=spp, want_rgba=False)
+    px = [(x, y) for y in range(0, H, 7) for x in range(0, W, 9)]
+    col_w, t_w, id_w = orc.sample_pixels(px, sph, cam, p, spp, bvh=bvh)
+    col_b, t_b, id_b = orc.sample_pixels(px, sph, cam, p, spp, mesh=mesh)
+    assert np.array_equal(orc.fold_samples(col_w, 1), np.array([ref[y, x] for x, y in px]))
+    assert np.array_equal(col_w, col_b) and np.array_equal(t_w, t_b) and np.array_equal(id_w, id_b)
+    assert (id_w >= 0).mean() > 0.3 and (id_w[..., 0] >= -1).all()

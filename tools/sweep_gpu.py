@@ -52,7 +52,7 @@ acc, rgba = pt.alloc_frame(W, H)
 variants = []
 for v in a.variants.split(","):
     parts = v.split(":") + ["", "", "", "", "", "", "", ""]
-    variants.append((v, {"mega": g.KERNEL_MEGA_BVH2, "persist": g.KERNEL_PERSISTENT, "wide": g.KERNEL_MEGA_WIDE, "wave": g.KERNEL_WAVEFRONT}[parts[0]],
+    variants.append((v, {"mega": g.KERNEL_MEGA_BVH2, "persist": g.KERNEL_PERSISTENT, "wave": g.KERNEL_WAVEFRONT}[parts[0]],
                      int(parts[1]) if parts[1] else 16, int(parts[2]) if parts[2] else 64,
                      int(parts[3]) if parts[3] else 5, int(parts[4]) if parts[4] else 16, int(parts[5]) if parts[5] else 2, int(parts[6]) if parts[6] else 8,
                      int(parts[7]) if parts[7] else 3, int(parts[8]) if parts[8] else 2))

@@ -7,6 +7,11 @@
 //           lane's item per instruction (4 instructions serve the quad's 4 items), data is
 //           handed to the owner with DPP quad_perm moves
 //   mode 2: as mode 0 but 2 x dwordx4 (32-byte items: a compressed node)
+//   mode 8: TWO independent chains per lane (two 64-byte items in flight per lane: the memory-level parallelism a walk
+//           would have with a prefetched second item), items/s counts both
+//   mode 9: 80-byte items, packed (5 x dwordx4; 1.25 lines on average: a CWBVH-style 8-wide node)
+//   mode 10: a 64-byte item + a ONE-dword touch of another random item's line (a prefetch whose result is not waited for
+//           until the next iteration's loads retire: vmcnt is in order)
 //   mode 7: quad per item: the 4 lanes of a quad chase ONE chain, each lane loads one 16-byte piece of the
 //           item (one instruction per item, 16 lines per wave instruction); items/s counts quads
 // Dependent chain: the next index depends on the loaded data, like pointer chasing.
@@ -34,6 +39,21 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ it
     const int ql = threadIdx.x & 3;
     uint32_t idx = mix((MODE == 7 ? gid >> 2 : gid) * 2654435761u + 12345u) % n_items;
     float acc = 0.f;
+    float touch = 0.f;   // mode 10: the register the touch loads land in; never read while a load is in flight
+    if (MODE == 8) {
+        uint32_t idb = mix(gid * 40503u + 7u) % n_items;
+        for (int it = 0; it < iters; it++) {
+            const float4* p = items + (size_t)idx * 4;
+            const float4* r = items + (size_t)idb * 4;
+            const float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
+            acc += a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w + a2.x + a2.y + a2.z + a2.w + a3.x + a3.y + a3.z;
+            acc += b0.x + b0.y + b0.z + b0.w + b1.x + b1.y + b1.z + b1.w + b2.x + b2.y + b2.z + b2.w + b3.x + b3.y + b3.z;
+            idx = mix(idx ^ __float_as_uint(a3.w) ^ (uint32_t)it) % n_items;
+            idb = mix(idb ^ __float_as_uint(b3.w) ^ (uint32_t)it) % n_items;
+        }
+        out[gid] = acc;
+        return;
+    }
     for (int it = 0; it < iters; it++) {
         float4 q0, q1, q2, q3;
         if (MODE == 0) {
@@ -59,6 +79,15 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ it
             t += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
             q0 = make_float4(t, 0.f, 0.f, 0.f); q1 = q2 = make_float4(0.f, 0.f, 0.f, 0.f);
             q3 = make_float4(0.f, 0.f, 0.f, quad_bcast<3>(r.w));
+        } else if (MODE == 9) {  // 80 bytes, packed: 5 x dwordx4
+            const float4* p = items + (size_t)(idx % (n_items * 4u / 5u - 1u)) * 5;
+            const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+            q0 = make_float4(a.x + e.x, a.y + e.y, a.z + e.z, a.w + e.w); q1 = b; q2 = c; q3 = d;
+        } else if (MODE == 10) {
+            const float4* p = items + (size_t)idx * 4;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            const uint32_t j = mix(idx + 977u * (uint32_t)it) % n_items;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(touch) : "v"(items + (size_t)j * 4) : "memory");
         } else if (MODE == 6) {  // 128 bytes: 8 x dwordx4 (two consecutive items)
             const float4* p = items + (size_t)(idx & ~1u) * 4;
             const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g2 = p[6], h = p[7];
@@ -91,6 +120,7 @@ __global__ void __launch_bounds__(256, 8) k_gather(const float4* __restrict__ it
         acc += s;
         idx = mix(idx ^ __float_as_uint(q3.w) ^ (uint32_t)it) % n_items;
     }
+    if (MODE == 10) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" : "+v"(touch)); acc += touch * 0.f; }
     out[gid] = acc;
 }
 
@@ -126,17 +156,21 @@ int main(int argc, char** argv) {
                (unsigned long long)n * 64ull, it);
         return a > 0 ? 0 : 1;
     }
-    const uint32_t n_items = argc > 1 ? (uint32_t)atoi(argv[1]) : 1000000u;  // 64 MB
+    const uint32_t n_items = argc > 1 ? (uint32_t)strtoul(argv[1], nullptr, 10) : 1000000u;  // 64 MB
     const int iters = argc > 2 ? atoi(argv[2]) : 256;
     const int blocks = 256 * 8, threads = 256;
-    std::vector<float> h((size_t)n_items * 16);
+    // the table is a 64 MB pattern repeated (the values only feed the hash of the next index)
+    const size_t pat_items = n_items < 1000000u ? n_items : 1000000u;
+    std::vector<float> h(pat_items * 16);
     for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) * 1e-3f;
     float4* d_items; float* d_out;
-    hipMalloc(&d_items, h.size() * 4);
-    hipMalloc(&d_out, (size_t)blocks * threads * 4);
-    hipMemcpy(d_items, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    if (hipMalloc(&d_items, (size_t)n_items * 64) != hipSuccess || hipMalloc(&d_out, (size_t)blocks * threads * 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    for (size_t off = 0; off < n_items; off += pat_items) {
+        const size_t n = (n_items - off < pat_items ? n_items - off : pat_items);
+        (void)hipMemcpy((char*)d_items + off * 64, h.data(), n * 64, hipMemcpyHostToDevice);
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 8; mode++) {
+    for (int mode = 0; mode < 11; mode++) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             hipEventRecord(e0);
@@ -147,13 +181,16 @@ int main(int argc, char** argv) {
             else if (mode == 4) hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 5) hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 6) hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 8) hipLaunchKernelGGL(k_gather<8>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 9) hipLaunchKernelGGL(k_gather<9>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 10) hipLaunchKernelGGL(k_gather<10>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep > 0 && ms < best) best = ms;
         }
-        const double items_n = (double)blocks * threads * iters / (mode == 7 ? 4 : 1);
-        static const int bytes_of[8] = {64, 64, 32, 16, 32, 48, 128, 64};
+        const double items_n = (double)blocks * threads * iters / (mode == 7 ? 4 : 1) * (mode == 8 ? 2 : 1);
+        static const int bytes_of[11] = {64, 64, 32, 16, 32, 48, 128, 64, 64, 80, 64};
         const double bytes = items_n * bytes_of[mode];
         printf("mode %d: %.3f ms  %.1f Gitems/s  %.1f GB/s chip  %.1f GB/s per CU\n", mode, best, items_n / best / 1e6,
                bytes / best / 1e6, bytes / best / 1e6 / 256);
