@@ -15,9 +15,9 @@ launches one sample per displayed frame (BasicScene.cpp:404); a call with spp = 
 launches bit for bit, but traces the S samples as independent work items (the 1-spp-per-call rate
 is reported beside the headline as `mrays_per_s_1spp`).  With N > 1 the framebuffer is
 tile-split into interleaved 8-row stripes (stripe s belongs to rank s % N), every rank
-renders its stripes of the SAME frame with the scene replicated, and the display words are
+renders its stripes of the SAME frame with the scene replicated, the display words are
 gathered on rank 0 with RCCL each step (the reference copies the frame to the display
-every frame too, BasicScene.cpp:424-432).  Total work is fixed => "scaling": "strong".
+every frame too, BasicScene.cpp:424-432) and the float accumulator stripes once at the end.  Total work is fixed => "scaling": "strong".
 `--gpus N` without a torchrun environment starts the N ranks itself, as child processes.
 
 Rank 0 prints ONE JSON line.  Everything under oracle/ is used here only AFTER the timed region:
@@ -75,7 +75,11 @@ def parse():
                          "re-clusters the triangles on the device and keeps the tree with the smaller area cost in node visits)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still initialise torch.distributed over RCCL (backend nccl, world 1) and send every step's "
-                         "display words through the same all_gather_into_tensor / side-stream path the N > 1 runs use")
+                         "display words through the same gather-to-root / side-stream path the N > 1 runs use")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not collect HBM traffic live (child runs of this script under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps: timed steps only
+    ap.add_argument("--big-parity-spp", type=int, default=2, help="samples of the big scene's in-run parity frame against the oracle (0 = skip)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N>1 dry run on a ONE-GPU box: every rank uses cuda:0, gloo backend, stripes gathered "
                          "through host memory (validates the multi-rank code path, not its speed)")
@@ -155,6 +159,47 @@ def gather_bound(table_bytes):
     out = subprocess.run([exe, "--json", str(n_items), "256"], capture_output=True, text=True, timeout=120)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     return json.loads(line[-1]) if out.returncode == 0 and line else None
+
+
+def pmc_live(kernel_family, extra_args, timeout=240):
+    """HBM-side traffic per launch of one kernel family, measured NOW for the running sources: this script is run again as a
+    CHILD under `rocprofv3 --pmc <counter>` (one pass per counter: FETCH_SIZE and WRITE_SIZE do not fit one pass,
+    MI355X_MICROARCH.md "rocprofv3 PMC slots"), timed steps only.  FETCH_SIZE is raw (TCC_EA0_RDREQ x 64 B: exact for 64-byte
+    gathers, HALF the bytes of a wide coalesced stream on gfx950 — the x2 figure is kept beside it); WRITE_SIZE is exact.
+    Returns None when rocprofv3 is not there or a pass fails (the committed profiles/ figure is quoted instead)."""
+    import csv
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k, None)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(td, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--steps", "4", "--warmup", "2", "--cpu-frames", "0", "--no-cpu-reference", "--no-extra", "--no-pmc"] + extra_args
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            except Exception:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    head = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    if row["Counter_Name"] != counter or head.split("<")[0] != kernel_family:
+                        continue
+                    if "<" in head and head.split("<")[-1].split(",")[0].strip() == "true":   # instrumented instantiation
+                        continue
+                    vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None
+            out[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
+    fs, ws = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
+    return {"fetch_bytes_raw": int(fs), "fetch_bytes_x2": int(2 * fs), "write_bytes": int(ws), "hbm_bytes_per_launch": int(fs + ws),
+            "launches_profiled": out["FETCH_SIZE"][1], "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this bench, same sources"}
 
 
 def spawn_ranks(a):
@@ -291,7 +336,7 @@ def main():
                 ev_gather[k].record(side)
                 buf.record_stream(side)
         elif not a.rehearse:   # display words of the finished stripes -> rank 0 (RCCL over xGMI)
-            staging[k] = tile_split.gather_stripes(buf, layout, dst=0, staging=staging[k])
+            staging[k] = tile_split.gather_stripes(buf, layout, dst=0, staging=staging[k], force=a.force_dist)
         else:
             host = buf.cpu()
             staging[k] = tile_split.gather_stripes(host, layout, dst=0, staging=staging[k])
@@ -306,11 +351,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_steps, first, params=base, spp=a.spp, fresh=False):
+    def timed(n_steps, first, params=base, spp=a.spp, fresh=False, per_step=None, sync_each=False):
+        """wall time of n_steps steps between barrier + synchronize; per_step (a list) also receives every step's device time
+        from events on the launch stream (the median is reported beside the mean); sync_each: pt_sync before every call,
+        the reference host's own loop (BasicScene.cpp:395)"""
         barrier()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if per_step is not None else None
         t0 = time.perf_counter()
+        if evs:
+            evs[0].record(stream)
         for k in range(n_steps):
+            if sync_each:
+                pt.sync()
             step(first + k, params, spp=spp, fresh=fresh)
+            if evs:
+                evs[k + 1].record(stream)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -319,6 +374,8 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if a.rehearse else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+        if evs:
+            per_step.extend(evs[k].elapsed_time(evs[k + 1]) for k in range(n_steps))
         return dt
 
     # ------------------------------------------------------------------ the timed region
@@ -330,7 +387,13 @@ def main():
     torch.cuda.synchronize()
     for k in range(a.warmup):
         step(k)
-    dt = timed(a.steps, a.warmup)
+    step_ms = []
+    dt = timed(a.steps, a.warmup, per_step=step_ms)
+    if a.pmc_child:   # the run rocprofv3 wraps (pmc_live): nothing but the timed steps
+        if rank == 0:
+            print(json.dumps({"pmc_child": True, "ms_per_step": round(dt / a.steps * 1e3, 4)}))
+        pt.close()
+        return
 
     # ---- everything below is outside the timed region ------------------------------------------
     # device time by stage (HIP events recorded by the library on the launch stream, PT_OPT_TIMING)
@@ -344,7 +407,13 @@ def main():
             stage[name] = stage.get(name, 0.0) + ms / n_tm
     pt.set_option(g.OPT_TIMING, 0)
 
-    # exact segment / item counts of the timed frames: replay them instrumented
+    # exact segment / item counts of the timed frames: replay them instrumented — with the kernel that was TIMED (under
+    # PT_KERNEL_AUTO an instrumented call would otherwise run the persistent kernel whatever the decision was)
+    timed_kernel = a.kernel
+    if a.kernel == g.KERNEL_AUTO:
+        k_auto = pt.auto_choice()[0]
+        timed_kernel = k_auto if k_auto != g.KERNEL_AUTO else g.KERNEL_PERSISTENT
+    pt.set_option(g.OPT_KERNEL, timed_kernel)
     pt.set_option(g.OPT_COUNTERS, 1)
     seg = torch.zeros(6, dtype=torch.float64, device="cpu" if a.rehearse else dev)
     n_count = min(a.steps, 2)
@@ -357,6 +426,7 @@ def main():
             seg[j] += c[key]
         wstats = pt.wave_stats()
     pt.set_option(g.OPT_COUNTERS, 0)
+    pt.set_option(g.OPT_KERNEL, a.kernel)
     if world > 1:
         dist.all_reduce(seg)
     rays_per_step, paths_per_step, items_nodes, items_recs = (float(seg[j].item()) / n_count for j in (0, 1, 2, 3))
@@ -388,6 +458,9 @@ def main():
         settle(spp=1)
         n_1 = max(20, a.steps)
         extra["mrays_per_s_1spp"] = rate(n_1, timed(n_1, 1, spp=1), spp=1)
+        # ... and exactly the reference host's loop: cudaStreamSynchronize before every launch (BasicScene.cpp:395-404) —
+        # what a maintainer following INTEGRATION.md section 2 gets; no call ever overlaps the previous one's tail
+        extra["mrays_per_s_1spp_sync"] = rate(n_1, timed(n_1, 1, spp=1, sync_each=True), spp=1)
         if world == 1:
             for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT)):
                 pt.set_option(g.OPT_KERNEL, kern)
@@ -395,14 +468,29 @@ def main():
                 extra[f"mrays_per_s_{kname}"] = rate(n_x, timed(n_x, 1))
                 settle(spp=1)
                 extra[f"mrays_per_s_1spp_{kname}"] = rate(n_1, timed(n_1, 1, spp=1), spp=1)
+                extra[f"mrays_per_s_1spp_sync_{kname}"] = rate(n_1, timed(n_1, 1, spp=1, sync_each=True), spp=1)
             pt.set_option(g.OPT_KERNEL, a.kernel)
 
     merged_ok = None
+    accum_gather_ms = None
     if use_dist:
-        # rank 0 re-renders the last gathered frame alone and compares the display words
+        # the last step once more, fresh (sample_index 1: the frame does not depend on accumulated history), then what north_star
+        # names: the gather of the ACCUMULATED tiles (float accumulator stripes, 24.9 MB in all at 1080p) to rank 0, beside the
+        # per-step gather of the display words; rank 0 re-renders the frame alone and compares both buffers
         last = a.warmup + a.steps
-        step(last, fresh=True)   # sample_index 1: the frame does not depend on accumulated history
+        step(last, fresh=True)
         torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        if a.rehearse:
+            host_acc = accum.cpu()
+            tile_split.gather_stripes(host_acc, layout, dst=0)
+            if rank == 0:
+                accum.copy_(host_acc)
+        else:
+            tile_split.gather_stripes(accum, layout, dst=0, force=a.force_dist)
+        torch.cuda.synchronize()
+        accum_gather_ms = (time.perf_counter() - t0) * 1e3
         if rank == 0:
             solo = g.Params.from_buffer_copy(base)
             solo.part_index, solo.part_count = 0, 1
@@ -411,14 +499,15 @@ def main():
             rgba2 = torch.zeros_like(rgba)
             pt.launch_kernel(acc2.data_ptr(), rgba2.data_ptr(), cam, solo, a.spp)
             torch.cuda.synchronize()
-            merged_ok = bool(torch.equal(last_frame()[:H], rgba2[:H]))
+            merged_ok = bool(torch.equal(last_frame()[:H], rgba2[:H])) and bool(torch.equal(accum[:H], acc2[:H]))
 
     if rank == 0:
         value = total_rays / dt / 1e6
         out = {
             "metric": "Mrays/sec, cornell_dragon 1920x1080 (+ achieved GB/s against the memory roofline)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "ms_per_step_median": round(float(np.median(step_ms)), 4) if step_ms else None,
+            "timed_seconds": round(dt, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if a.rehearse else ""),
             "config": {"workload": f"{a.scene} ({mesh.n_tris} tris) {W}x{H} depth {a.depth} {a.mat} + "
                                    f"{'reference 8-sphere room' if n_sph else 'no spheres'}, {a.spp} spp per step",
@@ -427,10 +516,11 @@ def main():
                                "device_mb": round(info["device_bytes"] / 2 ** 20, 1), "built_on": "device" if a.device_build else "host", "tree": tree_note,
                                "area_cost_node_visits": None if tree_cost is None else round(tree_cost[0], 3)},
                        "parallelism": (f"tile-split x{world} ({rows}-row stripes, "
-                                       f"{'REHEARSAL: all ranks on one GPU, gloo all-gather through host memory' if a.rehearse else 'RCCL all-gather'}"
-                                       f" of RGBA8 every step{', overlapped with the next render' if overlap else ''})") if use_dist else "1 GPU",
+                                       f"{'REHEARSAL: all ranks on one GPU, gloo gather through host memory' if a.rehearse else 'RCCL gather to rank 0 (ncclSend/ncclRecv group)'}"
+                                       f" of RGBA8 every step{', overlapped with the next render' if overlap else ''}; float accumulator stripes gathered at the end)") if use_dist else "1 GPU",
                        "closed_scene": bool(closed), "rays_per_step": rays_per_step,
-                       "tile_split_equals_single_gpu": merged_ok},
+                       "tile_split_equals_single_gpu": merged_ok,
+                       "accumulator_gather_ms": None if accum_gather_ms is None else round(accum_gather_ms, 3)},
             "stage_ms": {k: round(v, 4) for k, v in stage.items() if v > 0},
         }
         out.update(extra)
@@ -440,56 +530,75 @@ def main():
         dom = max((k for k in ("frame", "extend", "shade") if stage.get(k, 0) > 0), key=lambda k: stage[k], default=None)
         launches = a.depth if dom in ("extend", "shade") else 1
         kname = {"frame": "k_trace_persist_bvh2" if a.kernel != 1 else "k_trace_mega_bvh2", "extend": "k_wf_extend", "shade": "k_wf_shade"}.get(dom)
-        roof = {"bound": "hbm", "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": kname, "launches_per_step": launches, "hbm_peak": HBM_PEAK_GBS}
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": kname, "launches_per_step": launches}
         if world == 1 and dom:
             kms = stage[dom] / launches
             roof["kernel_ms_avg"] = round(kms, 4)
-            # ACHIEVED = the bytes this kernel's algorithm moves per launch / its HIP-event duration.  Per unit:
-            # 64 B per item the walk fetches (wide node or triangle record, counted by the instrumented replay) + the
-            # kernel's own streams (extend: 32-B ray in, 8-B hit out per segment; persistent: 12-B sample colour per path).
+            # TRAFFIC = bytes at the L2 <-> fabric boundary per launch (FETCH_SIZE + WRITE_SIZE), measured for THESE sources:
+            # live child runs under rocprofv3 --pmc, else the committed profile when its source hash matches.
+            # ACHIEVED = traffic / the kernel's HIP-event duration; FRAC = achieved / 8 TB/s — the fraction of the HBM roofline
+            # the kernel really draws (north_star's figure).  Infinity-Cache hits are inside FETCH_SIZE (MI355X_MICROARCH.md),
+            # so on a scene that fits the 256 MB cache this is an UPPER bound of what reaches HBM.
+            scene_args = ["--scene", a.scene, "--width", str(W), "--height", str(H), "--spp", str(a.spp), "--depth", str(a.depth), "--mat", a.mat,
+                          "--kernel", str(timed_kernel)] + (["--no-spheres"] if a.no_spheres else []) + (["--device-build"] if a.device_build else []) + \
+                         (["--keep-hierarchy"] if a.keep_hierarchy else [])
+            tr = None
+            if not a.no_pmc and not a.no_extra:
+                try:
+                    tr = pmc_live(kname, scene_args)
+                except Exception as e:
+                    tr = None
+                    roof["pmc_live_error"] = str(e)[:120]
+            if tr is None:
+                f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+                if os.path.exists(f):
+                    try:
+                        j = json.load(open(f))
+                        w = j.get("kernels", {}).get(kname)
+                        if w and (a.scene, W, H, a.spp) == ("cornell_dragon_800k", 1920, 1080, 16):
+                            if j.get("source_sha") == source_sha():
+                                tr = dict(w, source="profiles/r03_pmc_traffic.json (rocprofv3 --pmc passes, same kernel sources)")
+                            else:
+                                roof["traffic_of_other_sources"] = {"hbm_bytes_per_launch": w.get("hbm_bytes_per_launch"),
+                                                                    "note": "profiles/r03_pmc_traffic.json was taken with other kernel sources: not used for frac"}
+                    except Exception:
+                        pass
+            if tr:
+                hb = tr["hbm_bytes_per_launch"]
+                roof["traffic"] = hb
+                roof["achieved"] = round(hb / (kms * 1e-3) / 1e9, 1)
+                roof["frac"] = round(hb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["traffic_detail"] = {k: tr[k] for k in ("fetch_bytes_raw", "fetch_bytes_x2", "write_bytes", "source") if k in tr}
+            # REQUESTED = the bytes this kernel's algorithm asks the memory system for per launch: 64 B per item the walk fetches
+            # (wide node or triangle record, counted by the instrumented replay of the timed kernel) + its own streams (extend:
+            # 32-B ray in, 8-B hit out per segment; persistent: 12-B sample colour per path).  Served mostly by L1 / L2.
             items = (items_nodes + items_recs) / launches
             stream_b = (rays_per_step * 40.0 / launches) if dom == "extend" else (12.0 * paths_per_step)
             req = items * 64.0 + stream_b
-            roof["achieved"] = round(req / (kms * 1e-3) / 1e9, 1)
-            roof["bytes_per_launch"] = int(req)
+            roof["requested"] = {"bytes_per_launch": int(req), "gbs": round(req / (kms * 1e-3) / 1e9, 1),
+                                 "over_hbm_peak": round(req / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic_over_requested": round(roof["traffic"] / req, 4) if roof["traffic"] else None}
             roof["items_per_ray"] = round((items_nodes + items_recs) / rays_per_step, 2)
             roof["gitems_per_s"] = round(items / (kms * 1e-3) / 1e9, 2)
             if wstats:
                 roof["lane_use"] = {"node_steps": round(wstats["act_node"] / max(1, 64 * wstats["it_node"]), 3),
                                     "record_steps": round(wstats["act_rec"] / max(1, 64 * wstats["it_rec"]), 3),
                                     "stack_overflows_per_ray": round(wstats["stack_overflows"] / max(1.0, rays_per_step), 4)}
-            # PEAK = what binds a per-lane walk whose scene sits in the caches: the rate at which the memory hierarchy serves
-            # DEPENDENT random 64-byte items to every lane of 8 waves/SIMD when every fetch is an L2 hit (tools/ubench_gather,
-            # run here as a child process: 2 MB table), x 64 B.  The HBM figures (8 TB/s spec) are quoted beside it: this
-            # 105 MB scene never reaches HBM for its items, only for the ray / hit streams.
+            # GATHER CEILING (secondary): the rate at which the memory hierarchy serves DEPENDENT random 64-byte items to every
+            # lane of 8 waves/SIMD when every fetch is an L2 hit (tools/ubench_gather, a child process: 2 MB table) — what can
+            # bind a per-lane walk over a cache-resident scene — and the same through a table of the scene's size.
             if not a.no_extra:
                 try:
                     gb = gather_bound(info["device_bytes"])
                 except Exception as e:
                     gb = {"error": str(e)[:100]}
                 if gb and "items_per_s" in gb:
-                    roof["peak"] = round(gb["items_per_s_l2_resident"] * 64.0 / 1e9, 1)
-                    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-                    roof["gather_bound"] = {"gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
-                                            "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
-                                            "table_mb": round(gb["table_bytes"] / 2 ** 20, 1),
-                                            "note": "every lane of 8 waves/SIMD chases random 64-B items: through a 2 MB table (every fetch an "
-                                                    "L2 hit: the ceiling of ANY per-lane walk = peak) and through a table of the scene's size "
-                                                    "(a walk with no locality at all)"}
-            # HBM-side traffic per launch from rocprofv3 --pmc passes: only quoted when collected for THESE kernel sources
-            tr = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(tr):
-                try:
-                    j = json.load(open(tr))
-                    w = j.get("kernels", {}).get(kname)
-                    if j.get("source_sha") == source_sha() and w and (a.scene, W, H, a.spp) == ("cornell_dragon_800k", 1920, 1080, 16):
-                        roof["traffic"] = w.get("hbm_bytes_per_launch")
-                        roof["hbm_measured"] = {"gbs": round(w["hbm_bytes_per_launch"] / (kms * 1e-3) / 1e9, 1),
-                                                "frac_of_hbm_peak": round(w["hbm_bytes_per_launch"] / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same kernel sources)"}
-                except Exception:
-                    pass
+                    roof["gather_ceiling"] = {"gbs": round(gb["items_per_s_l2_resident"] * 64.0 / 1e9, 1),
+                                              "gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
+                                              "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
+                                              "table_mb": round(gb["table_bytes"] / 2 ** 20, 1)}
+                    roof["frac_of_gather_ceiling"] = round(items / (kms * 1e-3) / gb["items_per_s_l2_resident"], 4)
         if world == 1 and a.cpu_frames > 0:
             cb, cnt, ref_acc = cpu_baseline(g, bvh if bvh is not None else g.Bvh(mesh), sph, cam, base, a.warmup * a.spp, a.cpu_frames, a.spp)
             out["cpu_baseline"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in cb.items()}
@@ -517,11 +626,12 @@ def main():
                                           "nodes_per_ray": round(cnt["inner"] / cnt["rays"], 2), "tris_per_ray": round(cnt["tris"] / cnt["rays"], 2),
                                           "gbs_whole_step": round(alg_step / (step_ms * 1e-3) / 1e9, 1),
                                           "over_hbm_peak": round(alg_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        roof["note"] = ("achieved = bytes the dominant kernel's walk requests per launch (items x 64 B + its streams) / its HIP-event duration; "
-                        "peak = the measured rate of dependent 64-B gathers when every fetch hits L2 (the bound that can bind a walk over a "
-                        "cache-resident scene), so frac <= 1; hbm_peak = 8 TB/s spec, hbm_measured = PMC traffic of these kernel sources; "
-                        "algorithmic_8d = SURVEY 8(d)'s reference-layout bytes over the whole step, which caches serve (may exceed the HBM peak); "
-                        "big_scene repeats the exercise with a 1.2 GB item buffer that does not fit the Infinity Cache")
+        roof["note"] = ("traffic = PMC bytes at the L2<->fabric boundary per launch of the dominant kernel (FETCH_SIZE raw + WRITE_SIZE, measured for "
+                        "these sources); achieved = traffic / the kernel's HIP-event duration; peak = 8 TB/s (HBM3E spec); frac = achieved / peak. "
+                        "requested = what the walk asks for (items x 64 B + streams; caches serve most of it); gather_ceiling / frac_of_gather_ceiling "
+                        "= the measured L2-resident dependent-gather rate and the walk's share of it; algorithmic_8d = SURVEY 8(d)'s "
+                        "reference-layout bytes over the whole step (served by caches: may exceed the HBM peak).  roofline_hbm_scene repeats "
+                        "the exercise on a 1.2 GB item buffer that does not fit the 256 MB Infinity Cache")
         out["roofline"] = roof
         if world == 1 and not a.no_cpu_reference:
             try:
@@ -567,30 +677,82 @@ def main():
             bc = pt.counters()
             pt.set_option(g.OPT_COUNTERS, 0)
             bdom = max((k for k in ("frame", "extend") if bst.get(k, 0) > 0), key=lambda k: bst[k])
+            b_launches = a.depth if bdom == "extend" else 1
+            b_kname = "k_wf_extend" if bdom == "extend" else "k_trace_persist_bvh2"
+            b_kms = bst[bdom] / b_launches
             b_items = bc["inner"] + bc["tris"]
             b_stream = bc["rays"] * 40.0 if bdom == "extend" else 12.0 * bc["paths"]
+            b_req = (b_items * 64.0 + b_stream) / b_launches
             out["big_scene"] = {"workload": f"cornell_dragon_6400k ({big.n_tris} tris) {W}x{H} depth {a.depth} {a.mat} + sphere room, {a.spp} spp per step",
                                 "device_mb": round(binfo["device_bytes"] / 2 ** 20, 1), "device_build_ms": round(b_ms, 1),
                                 "mrays_per_s": round(bc["rays"] * n_b / dtb / 1e6, 1), "ms_per_step": round(dtb / n_b * 1e3, 3),
                                 "stage_ms": {k: round(v, 3) for k, v in bst.items() if v > 0},
-                                "items_per_ray": round(b_items / bc["rays"], 2),
-                                "requested_gbs": round((b_items * 64.0 + b_stream) / (bst[bdom] * 1e-3) / 1e9, 1),
-                                "hbm_frac_of_peak_if_all_missed": round((b_items * 64.0 + b_stream) / (bst[bdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            trb = os.path.join(ROOT, "profiles", "r02_big_scene_pmc_traffic.json")
-            if os.path.exists(trb) and bdom == "extend":
-                jb = json.load(open(trb))
-                wb = jb.get("kernels", {}).get("k_wf_extend")
-                if jb.get("source_sha") == source_sha() and wb and (W, H, a.spp, a.depth) == (1920, 1080, 16, 4):
-                    per_launch_ms = bst["extend"] / a.depth
-                    out["big_scene"]["hbm_measured"] = {"bytes_per_extend_launch": wb["hbm_bytes_per_launch"],
-                                                        "gbs": round(wb["hbm_bytes_per_launch"] / (per_launch_ms * 1e-3) / 1e9, 1),
-                                                        "frac_of_hbm_peak": round(wb["hbm_bytes_per_launch"] / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                        "source": "profiles/r02_big_scene_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE raw = TCC_MISS x 64 B for gathers, + WRITE_SIZE; same kernel sources)"}
+                                "items_per_ray": round(b_items / bc["rays"], 2)}
+            # the roofline record of the workload that does leave the caches: same fields as `roofline`
+            rb = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": b_kname,
+                  "launches_per_step": b_launches, "kernel_ms_avg": round(b_kms, 4),
+                  "requested": {"bytes_per_launch": int(b_req), "gbs": round(b_req / (b_kms * 1e-3) / 1e9, 1),
+                                "over_hbm_peak": round(b_req / (b_kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                  "items_per_ray": round(b_items / bc["rays"], 2), "gitems_per_s": round(b_items / b_launches / (b_kms * 1e-3) / 1e9, 2)}
+            trb = None
+            if not a.no_pmc:
+                try:
+                    trb = pmc_live(b_kname, ["--scene", "cornell_dragon_6400k", "--device-build", "--width", str(W), "--height", str(H), "--spp", str(a.spp),
+                                             "--depth", str(a.depth), "--mat", a.mat, "--kernel", str(g.KERNEL_WAVEFRONT if bdom == "extend" else g.KERNEL_PERSISTENT)])
+                except Exception as e:
+                    rb["pmc_live_error"] = str(e)[:120]
+            if trb is None:
+                f = os.path.join(ROOT, "profiles", "r03_big_scene_pmc_traffic.json")
+                if os.path.exists(f):
+                    jb = json.load(open(f))
+                    wb = jb.get("kernels", {}).get(b_kname)
+                    if jb.get("source_sha") == source_sha() and wb and (W, H, a.spp, a.depth) == (1920, 1080, 16, 4):
+                        trb = dict(wb, source="profiles/r03_big_scene_pmc_traffic.json (rocprofv3 --pmc passes, same kernel sources)")
+            if trb:
+                rb["traffic"] = trb["hbm_bytes_per_launch"]
+                rb["achieved"] = round(trb["hbm_bytes_per_launch"] / (b_kms * 1e-3) / 1e9, 1)
+                rb["frac"] = round(trb["hbm_bytes_per_launch"] / (b_kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                rb["requested"]["traffic_over_requested"] = round(trb["hbm_bytes_per_launch"] / b_req, 4)
+                rb["traffic_detail"] = {k: trb[k] for k in ("fetch_bytes_raw", "fetch_bytes_x2", "write_bytes", "source") if k in trb}
             gb = gather_bound(binfo["device_bytes"])
             if gb and "items_per_s" in gb:
-                out["big_scene"]["gather_bound"] = {"gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
-                                                    "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
-                                                    "frac": round(b_items / (bst[bdom] * 1e-3) / gb["items_per_s_l2_resident"], 4)}
+                rb["gather_ceiling"] = {"gbs": round(gb["items_per_s_l2_resident"] * 64.0 / 1e9, 1),
+                                        "gitems_per_s_l2_resident": round(gb["items_per_s_l2_resident"] / 1e9, 2),
+                                        "gitems_per_s_uniform_over_scene": round(gb["items_per_s"] / 1e9, 2),
+                                        "table_mb": round(gb["table_bytes"] / 2 ** 20, 1)}
+                rb["frac_of_gather_ceiling"] = round(b_items / b_launches / (b_kms * 1e-3) / gb["items_per_s_l2_resident"], 4)
+                rb["over_uniform_gather_rate"] = round(b_items / b_launches / (b_kms * 1e-3) / gb["items_per_s"], 4)
+            rb["note"] = "same fields as `roofline`, for cornell_dragon_6400k (1.2 GB of items: beyond the 256 MB Infinity Cache); the tree is the device builder's"
+            out["roofline_hbm_scene"] = rb
+            # in-run parity of this workload: one frame of `--big-parity-spp` samples over the DEVICE tree against the oracle's walk
+            # over a HOST tree of the same mesh (checker, after every timed region), + a ray batch against brute force
+            if a.big_parity_spp > 0:
+                import orc
+                pb = g.Params.from_buffer_copy(base)
+                pb.frame, pb.sample_index = 7, 1
+                acc_b = torch.zeros_like(accum)
+                pt.launch_kernel(acc_b.data_ptr(), rgba.data_ptr(), cam, pb, a.big_parity_spp)
+                torch.cuda.synchronize()
+                got_b = acc_b[:H].cpu().numpy()
+                t0 = time.perf_counter()
+                hb = g.Bvh(big, split_alpha=-1.0)
+                t_build = time.perf_counter() - t0
+                ref_b, _, cnt_b = orc.render(hb, sph, cam, pb, spp=a.big_parity_spp, want_rgba=False)
+                d_b = got_b.astype(np.float64) - ref_b
+                lo_b, hi_b = big.bounds()
+                rays_b = orc.random_rays(2048, lo_b, hi_b, seed=5)
+                d_rays = torch.from_numpy(rays_b).to(dev)
+                d_t = torch.empty(len(rays_b), dtype=torch.float32, device=dev)
+                d_i = torch.empty(len(rays_b), dtype=torch.int32, device=dev)
+                pt.trace_rays(d_rays.data_ptr(), len(rays_b), True, d_t.data_ptr(), d_i.data_ptr(), None)
+                torch.cuda.synchronize()
+                tb_, ib_, _ = orc.trace_brute(big, rays_b)
+                out["big_scene"]["parity"] = {"l2": float(np.sqrt(np.mean(np.sum(d_b ** 2, axis=-1)))),
+                                              "n_diff": int(np.any(got_b != ref_b, axis=-1).sum()), "pixels": W * H, "max_abs": float(np.abs(d_b).max()),
+                                              "ray_batch_vs_brute_force": {"rays": len(rays_b), "t_equal": bool(np.array_equal(d_t.cpu().numpy(), tb_)),
+                                                                           "id_equal": bool(np.array_equal(d_i.cpu().numpy(), ib_)), "hit_share": round(float((ib_ >= 0).mean()), 3)},
+                                              "what": f"device-built tree, {a.big_parity_spp} spp, vs oracle/pt_oracle.c over a host SAH tree of the same mesh "
+                                                      f"(built in {t_build:.1f} s), same seeds; + pt_trace_rays vs the brute-force loop"}
         except Exception as e:
             import traceback
             out["big_scene"] = {"error": str(e)[:200], "where": traceback.format_exc().strip().splitlines()[-3:]}

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_fold_samples(const KParams P) {
     if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
     for (uint32_t s = 0; s < P.spp; s++) {
         const float* c = P.samples + 3 * (s * plane + pix);
-        pt_accumulate(ax, ay, az, V3(c[0], c[1], c[2]), P.sample_index + s);
+        pt_accumulate(ax, ay, az, V3(pt_sld1(c), pt_sld1(c + 1), pt_sld1(c + 2)), P.sample_index + s);
     }
     acc[0] = ax; acc[1] = ay; acc[2] = az;
     if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);

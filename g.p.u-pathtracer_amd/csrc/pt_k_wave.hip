@@ -133,9 +133,10 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                         const uint32_t r = k * PT_SHARDS + (uint32_t)shard;
                         if (k < shard_regions && r < n_regions) {
-                            next = r * PT_REGION;
+                            const uint32_t rg = r + (uint32_t)P.wf.region0;   // global region number
+                            next = rg * PT_REGION;
                             if (FIRST) end = min(next + (uint32_t)PT_REGION, P.wf.n_slots);
-                            else end = next + (uint32_t)__builtin_amdgcn_readfirstlane(P.wf.cnt_in[r]);
+                            else end = next + (uint32_t)__builtin_amdgcn_readfirstlane(P.wf.cnt_in[rg]);
                             got = true;
                         } else {
                             shard = (shard + 1) & (PT_SHARDS - 1);
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                             live = true;
                         }
                     } else {
-                        const float4 a = P.wf.ray0_in[idx], b = P.wf.ray1_in[idx];
+                        const float4 a = pt_sld4(P.wf.ray0_in + idx), b = pt_sld4(P.wf.ray1_in + idx);
                         o = V3(a.x, a.y, a.z);
                         d = V3(a.w, b.x, b.y);
                         live = true;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
         if (live) {
             const bool fin = trav_run_wide<COUNT, true, false, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
             if (fin) {
-                P.wf.hit[idx] = make_float2(ts.h.t, __int_as_float(ts.h.rec));
+                pt_sst2(P.wf.hit + idx, make_float2(ts.h.t, __int_as_float(ts.h.rec)));
                 live = false;
                 if (COUNT) n_rays++;
             }
@@ -216,14 +217,15 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
     __shared__ int s_cnt2[PT_BLOCK / 64];
     wf_sphere_table();
-    const int n_in = FIRST ? PT_REGION : P.wf.cnt_in[blockIdx.x];
+    const uint32_t region = blockIdx.x + (uint32_t)P.wf.region0;
+    const int n_in = FIRST ? PT_REGION : P.wf.cnt_in[region];
     const bool last = P.wf.bounce + 1 >= P.depth;
     if (n_in == 0) {
-        if (!last && threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = 0;
-        if (NEE && threadIdx.x == 0) P.wf.s_cnt[blockIdx.x] = 0;
+        if (!last && threadIdx.x == 0) P.wf.cnt_out[region] = 0;
+        if (NEE && threadIdx.x == 0) P.wf.s_cnt[region] = 0;
         return;
     }
-    const size_t i = (size_t)blockIdx.x * PT_REGION + threadIdx.x;
+    const size_t i = (size_t)region * PT_REGION + threadIdx.x;
     bool have = (int)threadIdx.x < n_in;
     bool alive = false, tri_hit = false;
     PathState ps;
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
             path_begin_hashed(P, px, py, (uint64_t)pix, P.wf.hashes[s_idx], ps);
         } else {
-            const float4 a = P.wf.ray0_in[i], b = P.wf.ray1_in[i];
+            const float4 a = pt_sld4(P.wf.ray0_in + i), b = pt_sld4(P.wf.ray1_in + i);
             ps.o = V3(a.x, a.y, a.z);
             ps.d = V3(a.w, b.x, b.y);
             pix = __float_as_uint(b.z);
@@ -249,13 +251,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
                 sn &= 0x7fffffffu;
             }
             s_idx = sn >> 12;
-            ps.mask = V3(P.wf.mask_in[i], P.wf.mask_in[(size_t)P.wf.cap + i], P.wf.mask_in[2 * (size_t)P.wf.cap + i]);
+            ps.mask = V3(pt_sld1(P.wf.mask_in + i), pt_sld1(P.wf.mask_in + (size_t)P.wf.cap + i), pt_sld1(P.wf.mask_in + 2 * (size_t)P.wf.cap + i));
             ps.accu = V3(0.f, 0.f, 0.f);   // this segment's emission only: the running sum lives in the sample buffer
             ps.depth = P.wf.bounce;
             ps.rng = pt_rng_init(P.wf.hashes[s_idx], (uint64_t)pix);
             ps.rng.n = sn & 0xfffu;
         }
-        const float2 hh = P.wf.hit[i];
+        const float2 hh = pt_sld2(P.wf.hit + i);
         Hit h;
         h.t = hh.x;
         h.rec = __float_as_int(hh.y);
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0, NEE ? &req : nullptr);
             const v3 e = done ? col : ps.accu;   // mask * emission of this hit (accu entered as 0)
             if (FIRST) {   // accu = 0 (tracer.cu:48) + this hit's emission
-                smp[0] = 0.f + e.x; smp[1] = 0.f + e.y; smp[2] = 0.f + e.z;
+                pt_sst1(smp, 0.f + e.x); pt_sst1(smp + 1, 0.f + e.y); pt_sst1(smp + 2, 0.f + e.z);
             } else if (!(e.x == 0.f) || !(e.y == 0.f) || !(e.z == 0.f)) {
                 smp[0] += e.x; smp[1] += e.y; smp[2] += e.z;
             }
@@ -302,26 +304,26 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
         int n_sh;
         const int rs = wf_block_rank(req.want, n_sh, s_cnt2);
         if (req.want) {
-            const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)rs;
+            const size_t j = (size_t)region * PT_REGION + (size_t)rs;
             P.wf.s_ray0[j] = make_float4(req.o.x, req.o.y, req.o.z, req.d.x);
             P.wf.s_ray1[j] = make_float4(req.d.y, req.d.z, __uint_as_float(pix), __uint_as_float(s_idx));
             P.wf.s_con[j] = make_float4(req.contrib.x, req.contrib.y, req.contrib.z, req.t_max);
         }
-        if (threadIdx.x == 0) P.wf.s_cnt[blockIdx.x] = n_sh;
+        if (threadIdx.x == 0) P.wf.s_cnt[region] = n_sh;
     }
     if (last) return;   // every path ends with this bounce (tracer.cu:305)
     int total;
     const int r = wf_block_rank(alive, total, s_cnt);
     if (alive) {
-        const size_t j = (size_t)blockIdx.x * PT_REGION + (size_t)r;
-        P.wf.ray0_out[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x);
-        P.wf.ray1_out[j] = make_float4(ps.d.y, ps.d.z, __uint_as_float(NEE ? (pix | ((ps.nee_mask & 0xffu) << 24)) : pix),
-                                       __uint_as_float((s_idx << 12) | ps.rng.n | (NEE ? (ps.nee_mask >> 8) << 31 : 0u)));
-        P.wf.mask_out[j] = ps.mask.x;
-        P.wf.mask_out[(size_t)P.wf.cap + j] = ps.mask.y;
-        P.wf.mask_out[2 * (size_t)P.wf.cap + j] = ps.mask.z;
+        const size_t j = (size_t)region * PT_REGION + (size_t)r;
+        pt_sst4(P.wf.ray0_out + j, make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x));
+        pt_sst4(P.wf.ray1_out + j, make_float4(ps.d.y, ps.d.z, __uint_as_float(NEE ? (pix | ((ps.nee_mask & 0xffu) << 24)) : pix),
+                                              __uint_as_float((s_idx << 12) | ps.rng.n | (NEE ? (ps.nee_mask >> 8) << 31 : 0u))));
+        pt_sst1(P.wf.mask_out + j, ps.mask.x);
+        pt_sst1(P.wf.mask_out + (size_t)P.wf.cap + j, ps.mask.y);
+        pt_sst1(P.wf.mask_out + 2 * (size_t)P.wf.cap + j, ps.mask.z);
     }
-    if (threadIdx.x == 0) P.wf.cnt_out[blockIdx.x] = total;
+    if (threadIdx.x == 0) P.wf.cnt_out[region] = total;
 }
 
 // PT_FLAG_NEE: adds the contribution of every shadow ray that reached its light (nothing closer than t_max) to its path's
@@ -345,6 +347,7 @@ namespace ptmi {
 struct WaveLayout {
     size_t n_regions, cap, b_ray, b_mask, b_hit, b_cnt, b_hash, q_words, b_q, b_nee, need;
     bool nee;
+    int parts;   // 1, or the number of region ranges the call is pipelined in (PT_OPT_WAVE_PARTS)
 };
 
 // most RNG draws one bounce can make with these flags (path_shade_hit): DIFF 4, or 2 cosine-weighted (+ 3 for the light
@@ -368,7 +371,9 @@ static int wave_layout(pt_ctx* c, const KParams& P, int work_tiles, WaveLayout& 
     w.b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
     w.nee = (P.flags & PT_FLAG_NEE) != 0;
     if (w.nee && P.spp >= (1u << 19)) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_FLAG_NEE in the stage-split pipeline packs < 2^19 samples per call into a path record");
-    w.q_words = (size_t)P.depth * (w.nee ? 2 : 1) * PT_SHARDS * PT_SHARD_STRIDE;
+    // one set of queue counters per extend launch: per bounce (x 2 with shadow rays), or per (bounce, part) when pipelined
+    w.parts = (w.nee || c->opt_counters || c->opt_wave_parts <= 1 || w.n_regions < 64u * (size_t)c->opt_wave_parts) ? 1 : c->opt_wave_parts;
+    w.q_words = (size_t)P.depth * (w.nee ? 2 : (size_t)w.parts) * PT_SHARDS * PT_SHARD_STRIDE;
     w.b_q = w.q_words * 4;
     w.b_nee = w.nee ? 3 * w.b_ray + w.b_hit + w.b_cnt : 0;   // shadow records: s_ray0, s_ray1, s_con, s_hit, s_cnt
     w.need = 4 * w.b_ray + 2 * w.b_mask + w.b_hit + 2 * w.b_cnt + w.b_hash + w.b_q + w.b_nee;
@@ -402,6 +407,7 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     const size_t n_regions = w.n_regions, cap = w.cap, b_ray = w.b_ray, b_mask = w.b_mask, b_hit = w.b_hit, b_cnt = w.b_cnt, b_hash = w.b_hash;
     const size_t q_words = w.q_words, b_q = w.b_q;
     const bool nee = w.nee;
+    const int parts = w.parts;
     char* base = (char*)c->d_wave;
     float4* ray0[2] = {(float4*)base, (float4*)(base + b_ray)};
     float4* ray1[2] = {(float4*)(base + 2 * b_ray), (float4*)(base + 3 * b_ray)};
@@ -443,57 +449,115 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
 
     const size_t lds_ext = (size_t)(L.lstk == 24 ? 24 : 16) * PT_BLOCK * 4;
     const size_t lds_shade = 15 * PT_KSPHERES * 4;
-    for (uint32_t b = 0; b < P.depth; b++) {
-        const int g = (int)(b & 1u);
-        P.wf.bounce = b;
-        P.wf.ray0_in = ray0[g]; P.wf.ray1_in = ray1[g]; P.wf.mask_in = mask[g]; P.wf.cnt_in = cnt[g];
-        P.wf.ray0_out = ray0[g ^ 1]; P.wf.ray1_out = ray1[g ^ 1]; P.wf.mask_out = mask[g ^ 1]; P.wf.cnt_out = cnt[g ^ 1];
-        P.wf.queue = queues + (size_t)b * PT_SHARDS * PT_SHARD_STRIDE;
+    // launchers: the extend stage's persistent grid (resident blocks, at most `blocks_per_cu` per CU) and the shade stage's one
+    // block per region, for the launch parameters Q (a whole bounce or one part of it) on stream s
 #define PT_EXT(COUNT, OCC, LSTK, FIRST)                                                                           \
         do {                                                                                                      \
             int per_cu = 0;                                                                                       \
-            HIP_TRY(c, allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST>, lds_ext));                                 \
+            if (allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST>, lds_ext) != hipSuccess) return hipErrorInvalidValue; \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK, FIRST>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
                 per_cu = 1;                                                                                       \
-            per_cu = std::min(per_cu, c->opt_wave_blocks);                                                        \
-            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, n_regions)), \
-                               dim3(PT_BLOCK), lds_ext, st, P);                                                   \
+            per_cu = std::min(per_cu, blocks_per_cu);                                                             \
+            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, (size_t)Q.wf.n_regions)), \
+                               dim3(PT_BLOCK), lds_ext, s, Q);                                                    \
         } while (0)
-#define PT_EXT_ANY(FIRST)                                                                                         \
-        do {                                                                                                      \
-            if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24, FIRST); else PT_EXT(true, 8, 16, FIRST); }       \
-            else { if (L.lstk == 24) PT_EXT(false, 6, 24, FIRST); else PT_EXT(false, 8, 16, FIRST); }             \
-        } while (0)
+    auto launch_extend = [&](const KParams& Q, bool first, hipStream_t s, int blocks_per_cu) -> hipError_t {
+        if (first) {
+            if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24, true); else PT_EXT(true, 8, 16, true); }
+            else { if (L.lstk == 24) PT_EXT(false, 6, 24, true); else PT_EXT(false, 8, 16, true); }
+        } else {
+            if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24, false); else PT_EXT(true, 8, 16, false); }
+            else { if (L.lstk == 24) PT_EXT(false, 6, 24, false); else PT_EXT(false, 8, 16, false); }
+        }
+        return hipGetLastError();
+    };
+#undef PT_EXT
 #define PT_SHADE(COUNT, NEE, FIRST) \
-        hipLaunchKernelGGL((k_wf_shade<COUNT, NEE, FIRST>), dim3((unsigned)n_regions), dim3(PT_BLOCK), lds_shade, st, P)
-#define PT_SHADE_ANY(FIRST)                                                                                       \
-        do {                                                                                                      \
-            if (nee) { if (L.count) PT_SHADE(true, true, FIRST); else PT_SHADE(false, true, FIRST); }             \
-            else { if (L.count) PT_SHADE(true, false, FIRST); else PT_SHADE(false, false, FIRST); }               \
-        } while (0)
-        if (b == 0) PT_EXT_ANY(true); else PT_EXT_ANY(false);
+        hipLaunchKernelGGL((k_wf_shade<COUNT, NEE, FIRST>), dim3((unsigned)Q.wf.n_regions), dim3(PT_BLOCK), lds_shade, s, Q)
+    auto launch_shade = [&](const KParams& Q, bool first, hipStream_t s) -> hipError_t {
+        if (first) {
+            if (nee) { if (L.count) PT_SHADE(true, true, true); else PT_SHADE(false, true, true); }
+            else { if (L.count) PT_SHADE(true, false, true); else PT_SHADE(false, false, true); }
+        } else {
+            if (nee) { if (L.count) PT_SHADE(true, true, false); else PT_SHADE(false, true, false); }
+            else { if (L.count) PT_SHADE(true, false, false); else PT_SHADE(false, false, false); }
+        }
+        return hipGetLastError();
+    };
+#undef PT_SHADE
+    auto set_bounce = [&](KParams& Q, uint32_t b) {
+        const int g = (int)(b & 1u);
+        Q.wf.bounce = b;
+        Q.wf.ray0_in = ray0[g]; Q.wf.ray1_in = ray1[g]; Q.wf.mask_in = mask[g]; Q.wf.cnt_in = cnt[g];
+        Q.wf.ray0_out = ray0[g ^ 1]; Q.wf.ray1_out = ray1[g ^ 1]; Q.wf.mask_out = mask[g ^ 1]; Q.wf.cnt_out = cnt[g ^ 1];
+    };
+
+    if (parts > 1) {
+        // ---- pipelined in parts (PT_OPT_WAVE_PARTS): the call's regions are cut into `parts` ranges; all extend launches go to
+        // the caller's stream in the order (bounce, part), all shade launches to a second stream in the same order, tied by
+        // events: shade(part, b) after extend(part, b), extend(part, b + 1) after shade(part, b).  While the waves of
+        // extend(part + 1, b) walk the tree — latency-bound, HBM nearly idle — the blocks of shade(part, b) stream their path
+        // records through the block slots the extend grid leaves free (PT_OPT_WAVE_BLOCKS < 8 per CU).  Same records, same
+        // arithmetic, same order inside every region: the images do not change.
+        if (!c->wave_stream) {
+            int prio_lo = 0, prio_hi = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->wave_stream, hipStreamNonBlocking, prio_hi));
+        }
+        const size_t n_ev = (size_t)parts * 4;   // [generation of the bounce][part][extend done / shade done]
+        while (c->wave_ev.size() < n_ev) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->wave_ev.push_back(e);
+        }
+        auto ev = [&](uint32_t b, int part, int kind) { return c->wave_ev[((size_t)(b & 1u) * parts + (size_t)part) * 2 + (size_t)kind]; };
+        const int ext_blocks = std::min(c->opt_wave_blocks, 7);   // at least one block slot per CU stays free for the shade stage
+        for (uint32_t b = 0; b < P.depth; b++) {
+            for (int part = 0; part < parts; part++) {
+                KParams Q = P;
+                set_bounce(Q, b);
+                const size_t r0 = n_regions * (size_t)part / (size_t)parts, r1 = n_regions * (size_t)(part + 1) / (size_t)parts;
+                Q.wf.region0 = (int)r0;
+                Q.wf.n_regions = (int)(r1 - r0);
+                Q.wf.queue = queues + ((size_t)b * parts + (size_t)part) * PT_SHARDS * PT_SHARD_STRIDE;
+                if (b > 0) HIP_TRY(c, hipStreamWaitEvent(st, ev(b - 1, part, 1), 0));        // this part's records of the last bounce are shaded
+                if (span_begin(c, st) != PT_OK) return PT_ERR_DEVICE;
+                HIP_TRY(c, launch_extend(Q, b == 0, st, ext_blocks));
+                if (span_end(c, PT_STAGE_EXTEND, st) != PT_OK) return PT_ERR_DEVICE;
+                HIP_TRY(c, hipEventRecord(ev(b, part, 0), st));
+                HIP_TRY(c, hipStreamWaitEvent(c->wave_stream, ev(b, part, 0), 0));
+                if (span_begin(c, c->wave_stream) != PT_OK) return PT_ERR_DEVICE;
+                HIP_TRY(c, launch_shade(Q, b == 0, c->wave_stream));
+                if (span_end(c, PT_STAGE_SHADE, c->wave_stream) != PT_OK) return PT_ERR_DEVICE;
+                HIP_TRY(c, hipEventRecord(ev(b, part, 1), c->wave_stream));
+            }
+        }
+        for (int part = 0; part < parts; part++)   // the fold (caller's stream) needs every part's last shade
+            HIP_TRY(c, hipStreamWaitEvent(st, ev(P.depth - 1, part, 1), 0));
+        if (stage_mark(c, PT_STAGE_NONE) != PT_OK) return PT_ERR_DEVICE;   // the launches above were timed one by one (spans)
+        return PT_OK;
+    }
+
+    for (uint32_t b = 0; b < P.depth; b++) {
+        set_bounce(P, b);
+        P.wf.region0 = 0;
+        P.wf.n_regions = (int)n_regions;
+        P.wf.queue = queues + (size_t)b * PT_SHARDS * PT_SHARD_STRIDE;
+        HIP_TRY(c, launch_extend(P, b == 0, st, c->opt_wave_blocks));
         if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
-        if (b == 0) PT_SHADE_ANY(true); else PT_SHADE_ANY(false);
-        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, launch_shade(P, b == 0, st));
         if (stage_mark(c, PT_STAGE_SHADE) != PT_OK) return PT_ERR_DEVICE;
         if (nee) {   // this bounce's shadow rays: the same extend kernel over the shadow records, then the resolve
             KParams S = P;
             S.wf.ray0_in = P.wf.s_ray0; S.wf.ray1_in = P.wf.s_ray1; S.wf.cnt_in = P.wf.s_cnt; S.wf.hit = P.wf.s_hit;
             S.wf.queue = queues + ((size_t)P.depth + b) * PT_SHARDS * PT_SHARD_STRIDE;
-            const KParams keep = P;
-            P = S;
-            PT_EXT_ANY(false);
-            P = keep;
+            HIP_TRY(c, launch_extend(S, false, st, c->opt_wave_blocks));
             if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;
             hipLaunchKernelGGL(k_wf_resolve, dim3((unsigned)n_regions), dim3(PT_BLOCK), 0, st, P);
             HIP_TRY(c, hipGetLastError());
             if (stage_mark(c, PT_STAGE_SHADE) != PT_OK) return PT_ERR_DEVICE;
         }
     }
-#undef PT_EXT
-#undef PT_EXT_ANY
-#undef PT_SHADE
-#undef PT_SHADE_ANY
     return PT_OK;
 }
 

@@ -58,7 +58,8 @@ struct KWave {
     unsigned int* queues_all;     // k_wf_prepare: every bounce's counters, zeroed
     uint32_t queues_words;
     uint32_t cap;                 // slots per plane (regions * 256)
-    int n_regions;
+    int n_regions;                // regions of THIS launch: the whole call's, or one part's when the call is pipelined in parts
+    int region0;                  // first region of this launch (0 unless pipelined)
     uint32_t n_slots;             // (sample, pixel) slots of the call: work tiles * 64 (bounce 0 works on slots, not records)
     // PT_FLAG_NEE: the shadow-ray records a shade launch emits (region-compacted like the survivors), traced by another
     // extend launch and resolved by k_wf_resolve: s_ray0/s_ray1 as ray0/ray1, s_con = (contribution rgb, t_max), s_hit

@@ -35,6 +35,61 @@ __device__ __forceinline__ v3 vcross(v3 a, v3 b) {
 // glm::normalize = v * (1/sqrt(dot(v,v)))
 __device__ __forceinline__ v3 vnormalize(v3 a) { return vscale(a, 1.0f / sqrtf(vdot(a, a))); }
 
+// ---------------------------------------------------------------------------- streams
+// Loads / stores of data that is read once and written once per stage (path records, hit records, sample colours): marked
+// non-temporal (`nt`) so that the 2-4 GB a stage streams do not push the scene's items out of L2 / the Infinity Cache.
+#ifndef PT_STREAM_NT
+#define PT_STREAM_NT 1
+#endif
+typedef float pt_v4 __attribute__((ext_vector_type(4)));
+typedef float pt_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 pt_sld4(const float4* p) {
+#if PT_STREAM_NT
+    const pt_v4 v = __builtin_nontemporal_load((const pt_v4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void pt_sst4(float4* p, float4 a) {
+#if PT_STREAM_NT
+    const pt_v4 v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, (pt_v4*)p);
+#else
+    *p = a;
+#endif
+}
+__device__ __forceinline__ float2 pt_sld2(const float2* p) {
+#if PT_STREAM_NT
+    const pt_v2 v = __builtin_nontemporal_load((const pt_v2*)p);
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void pt_sst2(float2* p, float2 a) {
+#if PT_STREAM_NT
+    const pt_v2 v = {a.x, a.y};
+    __builtin_nontemporal_store(v, (pt_v2*)p);
+#else
+    *p = a;
+#endif
+}
+__device__ __forceinline__ float pt_sld1(const float* p) {
+#if PT_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void pt_sst1(float* p, float a) {
+#if PT_STREAM_NT
+    __builtin_nontemporal_store(a, p);
+#else
+    *p = a;
+#endif
+}
+
 // ---------------------------------------------------------------------------- RNG
 // uf::hash, GpuPathTracer/utilfun.cpp:380-389
 __device__ __forceinline__ uint64_t pt_wang64(uint64_t key) {

@@ -62,6 +62,26 @@ int stage_mark(pt_ctx* c, int kind) {
     c->stage_used++;
     return PT_OK;
 }
+
+int span_begin(pt_ctx* c, hipStream_t s) {
+    if (!c->opt_timing) return PT_OK;
+    if (c->spans_used == c->spans.size()) {
+        pt_ctx::Span sp = {0, nullptr, nullptr};
+        HIP_TRY(c, hipEventCreate(&sp.e0));
+        HIP_TRY(c, hipEventCreate(&sp.e1));
+        c->spans.push_back(sp);
+    }
+    HIP_TRY(c, hipEventRecord(c->spans[c->spans_used].e0, s));
+    return PT_OK;
+}
+
+int span_end(pt_ctx* c, int kind, hipStream_t s) {
+    if (!c->opt_timing) return PT_OK;
+    HIP_TRY(c, hipEventRecord(c->spans[c->spans_used].e1, s));
+    c->spans[c->spans_used].kind = kind;
+    c->spans_used++;
+    return PT_OK;
+}
 }  // namespace ptmi
 
 extern "C" {
@@ -123,6 +143,9 @@ int pt_destroy(pt_ctx* c) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     for (hipEvent_t e : c->stage_ev) (void)hipEventDestroy(e);
+    for (pt_ctx::Span& sp : c->spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
+    if (c->wave_stream) { (void)hipStreamSynchronize(c->wave_stream); (void)hipStreamDestroy(c->wave_stream); }
+    for (hipEvent_t e : c->wave_ev) (void)hipEventDestroy(e);
     for (pt_ctx::AutoPick& a : c->picks)
         for (hipEvent_t e : a.e) if (e) (void)hipEventDestroy(e);
     if (c->lights_ev) (void)hipEventDestroy(c->lights_ev);
@@ -192,6 +215,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             (option == PT_OPT_VOTE_NODE ? c->opt_vote_node : c->opt_vote_rec) = value;
             return PT_OK;
         case PT_OPT_OVERLAP: c->opt_overlap = value != 0; return PT_OK;
+        case PT_OPT_WAVE_PARTS:
+            if (value < 1 || value > 16) return fail(c, PT_ERR_INVALID, "pt_set_option: wave parts must be 1..16");
+            c->opt_wave_parts = value;
+            return PT_OK;
         case PT_OPT_WAVE_BLOCKS:
             if (value < 1 || value > 8) return fail(c, PT_ERR_INVALID, "pt_set_option: wave blocks must be 1..8 per CU");
             c->opt_wave_blocks = value;
@@ -694,6 +721,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (c->opt_timing) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         c->stage_used = 0;
+        c->spans_used = 0;
         if (stage_mark(c, PT_STAGE_NONE) != PT_OK) return PT_ERR_DEVICE;
     }
     const int lstk = c->opt_lstk ? c->opt_lstk : PT_STACK_CAP;   // any depth <= 64 works with every LDS window: deeper entries overflow
@@ -918,6 +946,13 @@ int pt_get_stage_ms(pt_ctx* c, float* out, int n) {
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->stage_ev[i - 1], c->stage_ev[i]));
         const int k = c->stage_kind[i];
+        if (k >= 0 && k < n) out[k] += ms;
+    }
+    for (size_t i = 0; i < c->spans_used; i++) {   // launches timed one by one (they may have run side by side: the sum can exceed the call)
+        float ms = 0.f;
+        HIP_TRY(c, hipEventSynchronize(c->spans[i].e1));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->spans[i].e0, c->spans[i].e1));
+        const int k = c->spans[i].kind;
         if (k >= 0 && k < n) out[k] += ms;
     }
     return PT_OK;

@@ -5,7 +5,8 @@ multi-GPU axis of BASELINE.json.  Pixels are independent and the RNG is keyed by
 pixel index, so the path needs NO collective while rendering: every rank holds the whole
 scene and renders the row stripes it owns (stripe s -> rank s % world, `rows` rows each,
 pt_params.part_*).  The only exchange is the gather of finished stripes on rank 0 when an
-image is wanted — RCCL over xGMI on GPUs (backend "nccl"), gloo in the CPU tests.
+image is wanted (display words every step, the float accumulator at the end) — RCCL over xGMI
+on GPUs (backend "nccl"), gloo in the CPU tests.
 
 Buffers are full-frame with the height padded to a whole number of stripes per rank, so a
 rank's stripes are a strided view [k, rank, :] of the frame and the gather needs one
@@ -44,27 +45,19 @@ class StripeLayout:
 
 
 def gather_stripes(frame, layout, dst=0, group=None, staging=None, force=False):
-    """Collect every rank's stripes of `frame` into rank `dst`'s copy of `frame` (in place).
+    """Collect every rank's stripes of `frame` into rank `dst`'s copy of `frame` (in place) — SURVEY 8(e)'s collective: a
+    GATHER TO ROOT.  `frame` is any full-frame buffer: the display words uint32[H][W] (gathered every step, 1 MB per
+    rank at 8 GPUs) or the float accumulator [H][W][3] (north_star's "accumulated tiles", 3.1 MB per rank at 8 GPUs,
+    gathered when the image is wanted).
 
-    GPU tensors: one all_gather_into_tensor (RCCL all-gather: 1/world of the frame per rank,
-    every rank's xGMI links carry one slice each way) + ONE permuted copy on `dst`.
-    CPU tensors (gloo tests / rehearsal): dist.gather + per-rank copies.
-    Runs on the CURRENT stream: call it under `torch.cuda.stream(side)` to overlap it with the
+    torch.distributed.gather on every backend: over RCCL (backend "nccl") it is one group of ncclSend / ncclRecv — each
+    peer sends its 1/world of the frame over its own xGMI link to the root, which receives on 7 links at once; nothing
+    goes to ranks that do not need it (an all-gather would move world x as many bytes for the same result).  gloo in the
+    CPU tests / rehearsal.  Runs on the CURRENT stream: call it under `torch.cuda.stream(side)` to overlap it with the
     next frame's render.  Returns the staging tensors so callers in a timed loop reuse them."""
     if layout.world == 1 and not force:   # force: a one-rank group still goes through the collective (bench --force-dist)
         return staging
     view = layout.frame_view(frame)
-    if frame.is_cuda:
-        if staging is None:
-            send = torch.empty_like(view[:, 0, :])
-            recv = torch.empty((layout.world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
-            staging = (send, recv)
-        send, recv = staging
-        send.copy_(view[:, layout.rank, :])
-        dist.all_gather_into_tensor(recv, send, group=group)
-        if layout.rank == dst:
-            view.copy_(recv.permute(1, 0, 2))
-        return staging
     if staging is None:
         send = torch.empty_like(view[:, 0, :])
         recv = [torch.empty_like(send) for _ in range(layout.world)] if layout.rank == dst else None

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""PT_OPT_WAVE_PARTS x PT_OPT_WAVE_BLOCKS on the bench step (or --scene ...): wall ms per step and the frame's crc.
+Usage: wf_parts.py [--scene cornell_dragon_800k] [--spp 16] [--device-build] parts:blocks ..."""
+import sys, time, zlib, os
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import gpu_pathtracer_amd as g
+args = sys.argv[1:]
+scene, spp, dev_build = "cornell_dragon_800k", 16, False
+cfgs = []
+while args:
+    a = args.pop(0)
+    if a == "--scene": scene = args.pop(0)
+    elif a == "--spp": spp = int(args.pop(0))
+    elif a == "--device-build": dev_build = True
+    else: cfgs.append(tuple(int(x) for x in a.split(":")))
+W, H = 1920, 1080
+pt = g.PathTracer(0)
+pt.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
+mesh = g.scene_mesh(scene)
+if dev_build:
+    pt.build_bvh(mesh)
+else:
+    pt.set_option(g.OPT_REBUILD, 2); pt.upload_bvh(g.Bvh(mesh)); pt.set_option(g.OPT_REBUILD, 0)
+pt.upload_spheres(g.reference_spheres())
+cam = g.default_camera(W, H); acc, rgba = pt.alloc_frame(W, H)
+def run(n, first=0):
+    for f in range(n):
+        p = g.default_params(W, H); p.frame, p.sample_index = (first + f) * spp, 1 + (first + f) * spp; p.flags = g.FLAG_WRITE_RGBA
+        pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+for rnd in range(2):
+    for parts, blocks in cfgs:
+        pt.set_option(g.OPT_WAVE_PARTS, parts); pt.set_option(g.OPT_WAVE_BLOCKS, blocks)
+        acc.zero(); run(3); pt.sync()
+        t0 = time.perf_counter(); run(10, 3); pt.sync()
+        dt = (time.perf_counter() - t0) / 10 * 1e3
+        crc = zlib.crc32(acc.download(np.float32, (H, W, 3)).tobytes())
+        pt.set_option(g.OPT_TIMING, 1); run(1, 13); pt.sync(); st = pt.stage_ms(); pt.set_option(g.OPT_TIMING, 0)
+        print(f"round {rnd} parts {parts} blocks {blocks}: {dt:.3f} ms/step crc {crc:08x} stages " + " ".join(f"{k} {v:.2f}" for k, v in st.items() if v > 0), flush=True)
+pt.close()
