@@ -212,14 +212,15 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
 // ------------------------------------------------------------------------------------------------
 // shade: one bounce of tracer.cu:98-296 for every live record of a region; see the file header.
 // FIRST: bounce 0 — lane = slot; the path starts here (camera ray, RNG) and the sample colour is written, not added to.
-template <bool COUNT, bool NEE, bool FIRST>
+// LAST: the path's final bounce (without PT_FLAG_NEE): only the hit's emission is still wanted (path_last_emission).
+template <bool COUNT, bool NEE, bool FIRST, bool LAST = false>
 __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
     __shared__ int s_cnt2[PT_BLOCK / 64];
     wf_sphere_table();
     const uint32_t region = blockIdx.x + (uint32_t)P.wf.region0;
     const int n_in = FIRST ? PT_REGION : P.wf.cnt_in[region];
-    const bool last = P.wf.bounce + 1 >= P.depth;
+    const bool last = LAST || P.wf.bounce + 1 >= P.depth;
     if (n_in == 0) {
         if (!last && threadIdx.x == 0) P.wf.cnt_out[region] = 0;
         if (NEE && threadIdx.x == 0) P.wf.s_cnt[region] = 0;
@@ -265,8 +266,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
         v3 tri_n = V3(0.f, 0.f, 0.f);
         tri_hit = h.t < PT_F32_MAX;
         if (tri_hit) {   // a triangle was hit: its id (v0.w) and un-normalised normal (4th piece)
-            const float4 q3 = P.sc.nodes[h.rec + 3];
-            tri_n = V3(q3.x, q3.y, q3.z);
+            if (!LAST) {
+                const float4 q3 = P.sc.nodes[h.rec + 3];
+                tri_n = V3(q3.x, q3.y, q3.z);
+            }
             h.tri = 0;
             if (P.tri_matid) h.tri = __float_as_int(P.sc.nodes[h.rec].w);
         }
@@ -283,7 +286,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             }
         } else {
             v3 col;
-            const bool done = path_shade_hit(P, ps, h, sh, tri_n, col, 0, NEE ? &req : nullptr);
+            const bool done = LAST ? true : path_shade_hit(P, ps, h, sh, tri_n, col, 0, NEE ? &req : nullptr);
+            if (LAST) col = path_last_emission(P, ps, h, sh, 0);
             const v3 e = done ? col : ps.accu;   // mask * emission of this hit (accu entered as 0)
             if (FIRST) {   // accu = 0 (tracer.cu:48) + this hit's emission
                 pt_sst1(smp, 0.f + e.x); pt_sst1(smp + 1, 0.f + e.y); pt_sst1(smp + 2, 0.f + e.z);
@@ -475,6 +479,10 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
 #define PT_SHADE(COUNT, NEE, FIRST) \
         hipLaunchKernelGGL((k_wf_shade<COUNT, NEE, FIRST>), dim3((unsigned)Q.wf.n_regions), dim3(PT_BLOCK), lds_shade, s, Q)
     auto launch_shade = [&](const KParams& Q, bool first, hipStream_t s) -> hipError_t {
+        if (!first && !nee && !L.count && Q.wf.bounce + 1 >= Q.depth) {   // the final bounce: emission only
+            hipLaunchKernelGGL((k_wf_shade<false, false, false, true>), dim3((unsigned)Q.wf.n_regions), dim3(PT_BLOCK), lds_shade, s, Q);
+            return hipGetLastError();
+        }
         if (first) {
             if (nee) { if (L.count) PT_SHADE(true, true, true); else PT_SHADE(false, true, true); }
             else { if (L.count) PT_SHADE(true, false, true); else PT_SHADE(false, false, true); }

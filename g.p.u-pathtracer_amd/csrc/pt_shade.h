@@ -366,6 +366,34 @@ __device__ __forceinline__ bool path_shade_hit(const KParams& P, PathState& ps, 
     return false;
 }
 
+// The LAST bounce of a path in the stage-split pipeline: nothing of path_shade_hit's BRDF work can reach the picture any more
+// (tracer.cu:305 returns accu after `depth` segments), only the hit's emission: returns mask * emit exactly as path_shade_hit
+// would have added it to an empty accu (the roulette switches end a path with the same accu).  No normal, no RNG draw.
+__device__ __forceinline__ v3 path_last_emission(const KParams& P, const PathState& ps, const Hit& h, const SceneHit& sh, int sph_tab) {
+    PT_KARGS(K);
+    v3 emit;
+    if (sh.geom == 1) {
+        if (sph_tab >= 0 && sh.sph_id < PT_KSPHERES) {
+            const float* t = (const float*)s_dyn + sph_tab + 11 * sh.sph_id;
+            emit = V3(t[4], t[5], t[6]);
+        } else {
+            const pt_sphere_d& s = P.sc.spheres[sh.sph_id];
+            emit = V3(s.emi[0], s.emi[1], s.emi[2]);
+        }
+        if (sh.sph_id < 8 && ((ps.nee_mask >> sh.sph_id) & 1u)) return V3(0.f, 0.f, 0.f);
+    } else {
+        if (K.tri_matid) {
+            const int row = K.tri_matid[h.tri];
+            const float4 m0 = K.mat_table[2 * row], m1 = K.mat_table[2 * row + 1];
+            emit = V3(m0.w, m1.x, m1.y);
+        } else {
+            emit = V3(K.tri_emi[0], K.tri_emi[1], K.tri_emi[2]);
+        }
+        if (ps.nee_mask & 0x100u) return V3(0.f, 0.f, 0.f);
+    }
+    return vadd(V3(0.f, 0.f, 0.f), vmul(ps.mask, emit));
+}
+
 // spheres + shading in one go (the kernels that shade in the lane that walked)
 __device__ __forceinline__ bool path_shade(const KParams& P, PathState& ps, const Hit& h, v3& col_out, int sph_tab = -1, NeeReq* nee = nullptr) {
     // the triangle's normal is asked for NOW so that its latency hides behind the sphere tests

@@ -25,6 +25,11 @@ extern __shared__ float4 s_dyn[];
 #ifndef PT_NODE_STEP_HOOK
 #define PT_NODE_STEP_HOOK(sc, a, w)
 #endif
+#ifndef PT_WALK_DECL_HOOK
+#define PT_WALK_DECL_HOOK()
+#define PT_NODE_END_HOOK(sc, cur)
+#define PT_WALK_EXIT_HOOK()
+#endif
 
 struct TravState {
     float idx, idy, idz, oodx, oody, oodz;
@@ -356,6 +361,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
     int cur = s.node, sp = s.sp;
     Hit h = s.h;
     const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
+    PT_WALK_DECL_HOOK();
     for (;;) {
         // phase vote: the wave runs ONE kind of step per iteration, the kind most live lanes are
         // waiting for; the others sit this iteration out.  Node and record lanes no longer both
@@ -396,6 +402,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
                 sp--;
             }
             if (COUNT && cur < 0) tc.leaves++;
+            PT_NODE_END_HOOK(sc, cur);
         } else {
             float4 q0, q1, q2;
             // Two thirds of the leaves hold two records (PT_OPT_LEAF_MAX 2), and the link says so: the second one is
@@ -473,6 +480,7 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
             }
         }
     }
+    PT_WALK_EXIT_HOOK();
     s.node = cur; s.sp = sp; s.h = h;
     return cur == PT_SENTINEL;
 }

@@ -22,4 +22,19 @@
     { float z = (w).ox;                                                                                                   \
       _Pragma("unroll") for (int e = 0; e < 32; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(z));                  \
       asm volatile("" :: "v"(z)); }
+#elif defined(PT_EXP_TOUCH)   // a lane whose node step ends on a LEAF touches the leaf's first record (one dword, never waited
+                              // for inside the loop): the record step that follows a vote or two later finds the line on its way
+#define PT_NODE_STEP_HOOK(sc, a, w)
+#define PT_WALK_DECL_HOOK() float touch_ = 0.f; asm volatile("" : "+v"(touch_))
+#define PT_NODE_END_HOOK(sc, cur)                                                                                         \
+    { if ((cur) < 0) { const float4* tp_ = (sc).nodes + (~(cur) & ~3);                                                      \
+          asm volatile("global_load_dword %0, %1, off" : "+v"(touch_) : "v"(tp_) : "memory"); } }
+#define PT_WALK_EXIT_HOOK() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" : "+v"(touch_)); }
+#elif defined(PT_EXP_TOUCH_ALL)   // every node step touches the item its lane goes to next (node or leaf)
+#define PT_NODE_STEP_HOOK(sc, a, w)
+#define PT_WALK_DECL_HOOK() float touch_ = 0.f; asm volatile("" : "+v"(touch_))
+#define PT_NODE_END_HOOK(sc, cur)                                                                                         \
+    { if ((cur) != PT_SENTINEL) { const float4* tp_ = (sc).nodes + ((cur) >= 0 ? (cur) : (~(cur) & ~3));                    \
+          asm volatile("global_load_dword %0, %1, off" : "+v"(touch_) : "v"(tp_) : "memory"); } }
+#define PT_WALK_EXIT_HOOK() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" : "+v"(touch_)); }
 #endif
