@@ -43,6 +43,8 @@ struct pt_ctx {
     uint64_t wide_root = 0;      // float4 index of the 4-wide tree's root, 0 = not built
     uint32_t wide_top_layout = 0, wide_depth = 0;
     uint64_t n_wide = 0;
+    uint64_t wide8_root = 0;     // float4 index of the 8-wide tree's root (PT_OPT_NODE_WIDTH), 0 = not built
+    uint32_t wide8_need = 0;     // stack entries its walk may need at once
     bool has_bvh = false;
     float build_ms = -1.f;       // device time of the last pt_build_bvh
     // options
@@ -74,6 +76,7 @@ struct pt_ctx {
     size_t wave_bytes = 0;
     int opt_wave_batch = 16;     // extend kernel: finished lanes that make a wave leave the walk to write hits / refill
     int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
+    int opt_node_width = 0;      // 4, 8, or 0 = 8 when the item buffer exceeds the Infinity Cache (PT_OPT_NODE_WIDTH; next upload)
     int opt_wave_parts = 1;      // pipeline the call in this many region ranges: shade(part) beside extend(part + 1) (PT_OPT_WAVE_PARTS)
     hipStream_t wave_stream = nullptr;     // the shade launches of a pipelined call
     std::vector<hipEvent_t> wave_ev;       // its stage-to-stage events

@@ -86,12 +86,14 @@ __device__ __forceinline__ bool wf_slot_pixel(const KParams& P, uint32_t slot, u
 // ------------------------------------------------------------------------------------------------
 // extend: the closest-hit walk (rows a5-a7) over the ray queue; see the file header.
 // FIRST: bounce 0 — a region is 256 consecutive slots and the ray is the slot's camera ray.
-template <bool COUNT, int OCC, int LSTK, bool FIRST>
+// W8: the scene's 8-wide tree (128-byte nodes, trav_run_wide8) instead of the 4-wide one.
+template <bool COUNT, int OCC, int LSTK, bool FIRST, bool W8 = false>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    TravOverflow<LSTK> stk_ovf;
-    TravStack<LSTK, PT_BLOCK> stk(__builtin_amdgcn_readfirstlane(tid & ~63), stk_ovf);
+    constexpr int CAP = W8 ? PT_STACK_CAP8 : PT_STACK_CAP;
+    TravOverflow<LSTK, CAP> stk_ovf;
+    TravStack<LSTK, PT_BLOCK, CAP> stk(__builtin_amdgcn_readfirstlane(tid & ~63), stk_ovf);
     const bool cull = P.cull != 0;
     const uint32_t n_regions = (uint32_t)P.wf.n_regions;
     const uint32_t shard_regions = (n_regions + PT_SHARDS - 1) / PT_SHARDS;
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                         d = V3(a.w, b.x, b.y);
                         live = true;
                     }
-                    if (live) trav_begin(ts, o, d, stk, P.sc.wide_root);
+                    if (live) trav_begin(ts, o, d, stk, W8 ? P.sc.wide8_root : P.sc.wide_root);
                 }
                 next += take;
                 served += take;
@@ -178,7 +180,8 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
         // ---- walk until `batch` lanes have finished (lanes that can get no more work do not count)
         const int n_dead = empty ? 64 - __popcll(busy) : 0;
         if (live) {
-            const bool fin = trav_run_wide<COUNT, true, false, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
+            const bool fin = W8 ? trav_run_wide8<COUNT, true, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch)
+                                : trav_run_wide<COUNT, true, false, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
             if (fin) {
                 pt_sst2(P.wf.hit + idx, make_float2(ts.h.t, __int_as_float(ts.h.rec)));
                 live = false;
@@ -451,21 +454,31 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     HIP_TRY(c, hipGetLastError());
     if (stage_mark(c, PT_STAGE_GENERATE) != PT_OK) return PT_ERR_DEVICE;
 
-    const size_t lds_ext = (size_t)(L.lstk == 24 ? 24 : 16) * PT_BLOCK * 4;
+    const size_t lds_ext = (size_t)(L.lstk == 24 && !P.sc.wide8_root ? 24 : 16) * PT_BLOCK * 4;
     const size_t lds_shade = 15 * PT_KSPHERES * 4;
     // launchers: the extend stage's persistent grid (resident blocks, at most `blocks_per_cu` per CU) and the shade stage's one
     // block per region, for the launch parameters Q (a whole bounce or one part of it) on stream s
-#define PT_EXT(COUNT, OCC, LSTK, FIRST)                                                                           \
+#define PT_EXT(COUNT, OCC, LSTK, FIRST, ...)                                                                      \
         do {                                                                                                      \
             int per_cu = 0;                                                                                       \
-            if (allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST>, lds_ext) != hipSuccess) return hipErrorInvalidValue; \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK, FIRST>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
+            if (allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST, ##__VA_ARGS__>, lds_ext) != hipSuccess) return hipErrorInvalidValue; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK, FIRST, ##__VA_ARGS__>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
                 per_cu = 1;                                                                                       \
             per_cu = std::min(per_cu, blocks_per_cu);                                                             \
-            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, (size_t)Q.wf.n_regions)), \
+            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST, ##__VA_ARGS__>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, (size_t)Q.wf.n_regions)), \
                                dim3(PT_BLOCK), lds_ext, s, Q);                                                    \
         } while (0)
     auto launch_extend = [&](const KParams& Q, bool first, hipStream_t s, int blocks_per_cu) -> hipError_t {
+        if (Q.sc.wide8_root) {   // the 8-wide tree, 16-entry LDS window; registers for 6 waves per SIMD (no spills) or, with PT_OPT_OCCUPANCY 8, for 8
+            if (L.occ >= 8) {
+                if (first) { if (L.count) PT_EXT(true, 8, 16, true, true); else PT_EXT(false, 8, 16, true, true); }
+                else { if (L.count) PT_EXT(true, 8, 16, false, true); else PT_EXT(false, 8, 16, false, true); }
+            } else {
+                if (first) { if (L.count) PT_EXT(true, 6, 16, true, true); else PT_EXT(false, 6, 16, true, true); }
+                else { if (L.count) PT_EXT(true, 6, 16, false, true); else PT_EXT(false, 6, 16, false, true); }
+            }
+            return hipGetLastError();
+        }
         if (first) {
             if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24, true); else PT_EXT(true, 8, 16, true); }
             else { if (L.lstk == 24) PT_EXT(false, 6, 24, true); else PT_EXT(false, 8, 16, true); }

@@ -7,22 +7,38 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import gpu_pathtracer_amd as g
 args = sys.argv[1:]
-scene, spp, dev_build = "cornell_dragon_800k", 16, False
+scene, spp, dev_build, node_width, occ, no_splits = "cornell_dragon_800k", 16, False, None, None, False
 cfgs = []
+keep = False
 while args:
     a = args.pop(0)
     if a == "--scene": scene = args.pop(0)
     elif a == "--spp": spp = int(args.pop(0))
     elif a == "--device-build": dev_build = True
+    elif a == "--node-width": node_width = int(args.pop(0))
+    elif a == "--occ": occ = int(args.pop(0))
+    elif a == "--no-splits": no_splits = True
+    elif a == "--keep": keep = True
     else: cfgs.append(tuple(int(x) for x in a.split(":")))
 W, H = 1920, 1080
 pt = g.PathTracer(0)
 pt.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
 mesh = g.scene_mesh(scene)
+if node_width is not None:
+    pt.set_option(g.OPT_NODE_WIDTH, node_width)
+if occ is not None:
+    pt.set_option(g.OPT_OCCUPANCY, occ)
+t0 = time.perf_counter()
 if dev_build:
     pt.build_bvh(mesh)
 else:
-    pt.set_option(g.OPT_REBUILD, 2); pt.upload_bvh(g.Bvh(mesh)); pt.set_option(g.OPT_REBUILD, 0)
+    bvh = g.Bvh(mesh, split_alpha=-1.0) if no_splits else g.Bvh(mesh)
+    t1 = time.perf_counter()
+    if not no_splits and not keep:
+        pt.set_option(g.OPT_REBUILD, 2)
+    pt.upload_bvh(bvh); pt.set_option(g.OPT_REBUILD, 0)
+    print(f"host build {t1 - t0:.1f} s, upload {time.perf_counter() - t1:.1f} s", flush=True)
+print("scene", pt.scene_info(), flush=True)
 pt.upload_spheres(g.reference_spheres())
 cam = g.default_camera(W, H); acc, rgba = pt.alloc_frame(W, H)
 def run(n, first=0):
@@ -36,6 +52,9 @@ for rnd in range(2):
         t0 = time.perf_counter(); run(10, 3); pt.sync()
         dt = (time.perf_counter() - t0) / 10 * 1e3
         crc = zlib.crc32(acc.download(np.float32, (H, W, 3)).tobytes())
-        pt.set_option(g.OPT_TIMING, 1); run(1, 13); pt.sync(); st = pt.stage_ms(); pt.set_option(g.OPT_TIMING, 0)
+        pt.set_option(g.OPT_TIMING, 1); run(1, 13); pt.sync(); run(1, 13); pt.sync(); st = pt.stage_ms(); pt.set_option(g.OPT_TIMING, 0)
+        if rnd == 0:
+            pt.set_option(g.OPT_COUNTERS, 1); run(1, 13); pt.sync(); c = pt.counters(); w = pt.wave_stats(); pt.set_option(g.OPT_COUNTERS, 0)
+            print(f"   per ray: nodes {c['inner'] / c['rays']:.2f} records {c['tris'] / c['rays']:.2f} leaves {c['leaves'] / c['rays']:.2f}; lane use node {w['act_node'] / max(1, 64 * w['it_node']):.3f} rec {w['act_rec'] / max(1, 64 * w['it_rec']):.3f} overflows/ray {w['stack_overflows'] / c['rays']:.4f}", flush=True)
         print(f"round {rnd} parts {parts} blocks {blocks}: {dt:.3f} ms/step crc {crc:08x} stages " + " ".join(f"{k} {v:.2f}" for k, v in st.items() if v > 0), flush=True)
 pt.close()
