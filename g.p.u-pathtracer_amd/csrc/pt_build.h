@@ -53,7 +53,6 @@ struct BuildArrays {
     unsigned int* stats;     // [0] wide nodes allocated [1] - [2] leaves [3] max binary depth
     unsigned int* level_cnt; // [66] frontier size of every wide level (level 0 = 1: the root)
     int2* frontier_a; int2* frontier_b;   // (inner node, wide slot)
-    unsigned long long* wkey;             // [n] per wide slot: (first record position of its subtree << 8) | wide level — pre-order key
 };
 
 __device__ __forceinline__ unsigned int ptb_ordered(float f) {
@@ -528,9 +527,6 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, con
     const int2 item = in[idx];
     const int rec_base = 4 * (B.n - 1);
     const int wide_base = rec_base + 4 * B.n;
-    // ascending (first record, level) is the PRE-ORDER of the wide tree: an ancestor shares its first record with its first
-    // descendants and sits on a lower level (k_wide_permute lays the nodes out in that order)
-    B.wkey[item.y] = ((unsigned long long)(unsigned int)B.first[item.x] << 8) | (unsigned long long)(unsigned int)level;
     int ref[4];
     PtBox cb[4];
     int cnt = 0;
@@ -579,34 +575,4 @@ __global__ void __launch_bounds__(PTB_BLOCK) k_collapse(const BuildArrays B, con
     float4* dst = B.items + (size_t)wide_base + 4 * (size_t)item.y;
     for (int k = 0; k < 4; k++) dst[k] = make_float4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
     }
-}
-
-// ---- depth-first layout of the wide nodes --------------------------------------------------------------------------------
-// k_collapse hands out wide slots level by level in arrival order, so a ray's way down the tree hops all over the node array.
-// Sorted by their pre-order key (radix sort of (key, slot)) subtrees are contiguous again, as in the host path's layout:
-// on a 1.2 GB item buffer the same tree renders 8 % faster (pages and lines a ray touches late lie close together); scenes that
-// fit the caches do not care.  rank[r] = old slot of the node that goes to position r.
-__global__ void __launch_bounds__(PTB_BLOCK) k_iota(int* __restrict__ v, int n) {
-    const int i = blockIdx.x * PTB_BLOCK + threadIdx.x;
-    if (i < n) v[i] = i;
-}
-
-__global__ void __launch_bounds__(PTB_BLOCK) k_wide_newpos(const int* __restrict__ rank, int n_wide, int* __restrict__ newpos) {
-    const int r = blockIdx.x * PTB_BLOCK + threadIdx.x;
-    if (r < n_wide) newpos[rank[r]] = r;
-}
-
-__global__ void __launch_bounds__(PTB_BLOCK) k_wide_permute(const float4* __restrict__ items, int wide_base, const int* __restrict__ rank,
-                                                            const int* __restrict__ newpos, int n_wide, float4* __restrict__ out) {
-    const int r = blockIdx.x * PTB_BLOCK + threadIdx.x;
-    if (r >= n_wide) return;
-    const float4* src = items + (size_t)wide_base + 4 * (size_t)rank[r];
-    float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-    auto remap = [&](float f) {
-        const int l = __float_as_int(f);
-        return l >= wide_base ? __int_as_float(wide_base + 4 * newpos[(l - wide_base) >> 2]) : f;
-    };
-    q2.z = remap(q2.z); q2.w = remap(q2.w); q3.x = remap(q3.x); q3.y = remap(q3.y);
-    float4* dst = out + 4 * (size_t)r;
-    dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
 }

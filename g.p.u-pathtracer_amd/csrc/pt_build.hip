@@ -96,7 +96,6 @@ int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t*
     HIP_TRY(c, tmp.get(&B.level_cnt, 68));
     HIP_TRY(c, tmp.get(&B.frontier_a, (size_t)n));
     HIP_TRY(c, tmp.get(&B.frontier_b, (size_t)n));
-    HIP_TRY(c, tmp.get(&B.wkey, (size_t)n));
     B.verts = d_verts;
     B.tris = d_tris_idx;
     if (id_map) {
@@ -216,32 +215,10 @@ int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t*
         }
         HIP_TRY(c, hipGetLastError());
     }
+    HIP_TRY(c, hipEventRecord(e1, st));
     unsigned int stats[4], level_cnt[68];
     HIP_TRY(c, hipMemcpyAsync(stats, B.stats, sizeof stats, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(level_cnt, B.level_cnt, sizeof level_cnt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipStreamSynchronize(st));
-    if (stats[0] > 2 && stats[0] <= (unsigned int)(n - 1) && level_cnt[std::min<unsigned int>(n_levels_max + 1, 67)] == 0) {   // a finished collapse
-        // depth-first layout of the wide nodes (k_wide_permute): sort the slots by their pre-order key, move the nodes, remap links
-        const int n_wide = (int)stats[0];
-        const int wide_base = 4 * (n - 1) + 4 * n;
-        unsigned long long* key_out = nullptr;
-        int *slot_in = B.val_in, *rank = B.parent_l, *newpos = B.parent_i;   // arrays of the finished hierarchy build, reused
-        float4* moved = nullptr;
-        HIP_TRY(c, tmp.get(&key_out, (size_t)n_wide));
-        HIP_TRY(c, tmp.get(&moved, 4 * (size_t)n_wide));
-        const dim3 gw((unsigned)((n_wide + PTB_BLOCK - 1) / PTB_BLOCK));
-        hipLaunchKernelGGL(k_iota, gw, blk, 0, st, slot_in, n_wide);
-        size_t sb = 0;
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, sb, B.wkey, key_out, slot_in, rank, n_wide, 0, 40, st));
-        char* stmp = nullptr;
-        HIP_TRY(c, tmp.get(&stmp, sb));
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(stmp, sb, B.wkey, key_out, slot_in, rank, n_wide, 0, 40, st));
-        hipLaunchKernelGGL(k_wide_newpos, gw, blk, 0, st, rank, n_wide, newpos);
-        hipLaunchKernelGGL(k_wide_permute, gw, blk, 0, st, items, wide_base, rank, newpos, n_wide, moved);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(items + (size_t)wide_base, moved, (size_t)n_wide * 64, hipMemcpyDeviceToDevice, st));
-    }
-    HIP_TRY(c, hipEventRecord(e1, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     uint32_t levels = 0;
     while (levels < 66 && level_cnt[levels] > 0) levels++;

@@ -43,8 +43,6 @@ struct pt_ctx {
     uint64_t wide_root = 0;      // float4 index of the 4-wide tree's root, 0 = not built
     uint32_t wide_top_layout = 0, wide_depth = 0;
     uint64_t n_wide = 0;
-    uint64_t wide8_root = 0;     // float4 index of the 8-wide tree's root (PT_OPT_NODE_WIDTH), 0 = not built
-    uint32_t wide8_need = 0;     // stack entries its walk may need at once
     bool has_bvh = false;
     float build_ms = -1.f;       // device time of the last pt_build_bvh
     // options
@@ -76,10 +74,6 @@ struct pt_ctx {
     size_t wave_bytes = 0;
     int opt_wave_batch = 16;     // extend kernel: finished lanes that make a wave leave the walk to write hits / refill
     int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
-    int opt_node_width = 0;      // 4, 8, or 0 = 8 when the item buffer exceeds the Infinity Cache (PT_OPT_NODE_WIDTH; next upload)
-    int opt_wave_parts = 1;      // pipeline the call in this many region ranges: shade(part) beside extend(part + 1) (PT_OPT_WAVE_PARTS)
-    hipStream_t wave_stream = nullptr;     // the shade launches of a pipelined call
-    std::vector<hipEvent_t> wave_ev;       // its stage-to-stage events
     // PT_KERNEL_AUTO: which stage layout is faster depends on the workload (long paths and many samples per call:
     // the stage-split pipeline; short paths or few samples: the persistent kernel), so the first two calls of a
     // configuration time one each (HIP events on the stream, buffers allocated before the timed span) and the following
@@ -119,10 +113,6 @@ struct pt_ctx {
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> stage_kind;
     size_t stage_used = 0;
-    // ... and, for launches that run on several streams at once (the pipelined stage-split call), one (start, end) pair per launch
-    struct Span { int kind; hipEvent_t e0, e1; };
-    std::vector<Span> spans;
-    size_t spans_used = 0;
 };
 
 namespace ptmi {
@@ -179,9 +169,6 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles);
 int wave_reserve(pt_ctx* c, const KParams& P, int work_tiles);   // path records for this call, allocated now
 // PT_OPT_TIMING: marks the end of a stage of the running call on the context's stream (no-op when timing is off)
 int stage_mark(pt_ctx* c, int kind_of_work_since_last_mark);
-// PT_OPT_TIMING for launches on any stream: span_begin before the launch, span_end(kind) after it, on the launch's stream
-int span_begin(pt_ctx* c, hipStream_t s);
-int span_end(pt_ctx* c, int kind, hipStream_t s);
 // device BVH builder (pt_build.hip)
 int build_bvh_impl(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris, int algo, bool* too_deep,
                    const int32_t* id_map = nullptr);

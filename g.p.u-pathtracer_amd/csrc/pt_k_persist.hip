@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                 }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
             } else if (P.samples) {
                 float* dst = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
-                dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+                pt_sst1(dst, col.x); pt_sst1(dst + 1, col.y); pt_sst1(dst + 2, col.z);   // read once, by the fold
                 if (COUNT) n_paths++;
                 phase = PH_IDLE;
             } else {

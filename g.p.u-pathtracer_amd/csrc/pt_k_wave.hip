@@ -86,14 +86,12 @@ __device__ __forceinline__ bool wf_slot_pixel(const KParams& P, uint32_t slot, u
 // ------------------------------------------------------------------------------------------------
 // extend: the closest-hit walk (rows a5-a7) over the ray queue; see the file header.
 // FIRST: bounce 0 — a region is 256 consecutive slots and the ray is the slot's camera ray.
-// W8: the scene's 8-wide tree (128-byte nodes, trav_run_wide8) instead of the 4-wide one.
-template <bool COUNT, int OCC, int LSTK, bool FIRST, bool W8 = false>
+template <bool COUNT, int OCC, int LSTK, bool FIRST>
 __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr int CAP = W8 ? PT_STACK_CAP8 : PT_STACK_CAP;
-    TravOverflow<LSTK, CAP> stk_ovf;
-    TravStack<LSTK, PT_BLOCK, CAP> stk(__builtin_amdgcn_readfirstlane(tid & ~63), stk_ovf);
+    TravOverflow<LSTK> stk_ovf;
+    TravStack<LSTK, PT_BLOCK> stk(__builtin_amdgcn_readfirstlane(tid & ~63), stk_ovf);
     const bool cull = P.cull != 0;
     const uint32_t n_regions = (uint32_t)P.wf.n_regions;
     const uint32_t shard_regions = (n_regions + PT_SHARDS - 1) / PT_SHARDS;
@@ -135,10 +133,9 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                         const uint32_t r = k * PT_SHARDS + (uint32_t)shard;
                         if (k < shard_regions && r < n_regions) {
-                            const uint32_t rg = r + (uint32_t)P.wf.region0;   // global region number
-                            next = rg * PT_REGION;
+                            next = r * PT_REGION;
                             if (FIRST) end = min(next + (uint32_t)PT_REGION, P.wf.n_slots);
-                            else end = next + (uint32_t)__builtin_amdgcn_readfirstlane(P.wf.cnt_in[rg]);
+                            else end = next + (uint32_t)__builtin_amdgcn_readfirstlane(P.wf.cnt_in[r]);
                             got = true;
                         } else {
                             shard = (shard + 1) & (PT_SHARDS - 1);
@@ -165,7 +162,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
                         d = V3(a.w, b.x, b.y);
                         live = true;
                     }
-                    if (live) trav_begin(ts, o, d, stk, W8 ? P.sc.wide8_root : P.sc.wide_root);
+                    if (live) trav_begin(ts, o, d, stk, P.sc.wide_root);
                 }
                 next += take;
                 served += take;
@@ -180,8 +177,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
         // ---- walk until `batch` lanes have finished (lanes that can get no more work do not count)
         const int n_dead = empty ? 64 - __popcll(busy) : 0;
         if (live) {
-            const bool fin = W8 ? trav_run_wide8<COUNT, true, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch)
-                                : trav_run_wide<COUNT, true, false, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
+            const bool fin = trav_run_wide<COUNT, true, false, true>(ts, P.sc, o, d, cull, stk, tc, n_dead, batch);
             if (fin) {
                 pt_sst2(P.wf.hit + idx, make_float2(ts.h.t, __int_as_float(ts.h.rec)));
                 live = false;
@@ -221,7 +217,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
     __shared__ int s_cnt2[PT_BLOCK / 64];
     wf_sphere_table();
-    const uint32_t region = blockIdx.x + (uint32_t)P.wf.region0;
+    const uint32_t region = blockIdx.x;
     const int n_in = FIRST ? PT_REGION : P.wf.cnt_in[region];
     const bool last = LAST || P.wf.bounce + 1 >= P.depth;
     if (n_in == 0) {
@@ -354,7 +350,6 @@ namespace ptmi {
 struct WaveLayout {
     size_t n_regions, cap, b_ray, b_mask, b_hit, b_cnt, b_hash, q_words, b_q, b_nee, need;
     bool nee;
-    int parts;   // 1, or the number of region ranges the call is pipelined in (PT_OPT_WAVE_PARTS)
 };
 
 // most RNG draws one bounce can make with these flags (path_shade_hit): DIFF 4, or 2 cosine-weighted (+ 3 for the light
@@ -378,9 +373,7 @@ static int wave_layout(pt_ctx* c, const KParams& P, int work_tiles, WaveLayout& 
     w.b_hash = (((size_t)P.spp * 8 + 255) / 256) * 256;
     w.nee = (P.flags & PT_FLAG_NEE) != 0;
     if (w.nee && P.spp >= (1u << 19)) return fail(c, PT_ERR_UNSUPPORTED, "pt_render: PT_FLAG_NEE in the stage-split pipeline packs < 2^19 samples per call into a path record");
-    // one set of queue counters per extend launch: per bounce (x 2 with shadow rays), or per (bounce, part) when pipelined
-    w.parts = (w.nee || c->opt_counters || c->opt_wave_parts <= 1 || w.n_regions < 64u * (size_t)c->opt_wave_parts) ? 1 : c->opt_wave_parts;
-    w.q_words = (size_t)P.depth * (w.nee ? 2 : (size_t)w.parts) * PT_SHARDS * PT_SHARD_STRIDE;
+    w.q_words = (size_t)P.depth * (w.nee ? 2 : 1) * PT_SHARDS * PT_SHARD_STRIDE;   // one set of queue counters per extend launch
     w.b_q = w.q_words * 4;
     w.b_nee = w.nee ? 3 * w.b_ray + w.b_hit + w.b_cnt : 0;   // shadow records: s_ray0, s_ray1, s_con, s_hit, s_cnt
     w.need = 4 * w.b_ray + 2 * w.b_mask + w.b_hit + 2 * w.b_cnt + w.b_hash + w.b_q + w.b_nee;
@@ -414,7 +407,6 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     const size_t n_regions = w.n_regions, cap = w.cap, b_ray = w.b_ray, b_mask = w.b_mask, b_hit = w.b_hit, b_cnt = w.b_cnt, b_hash = w.b_hash;
     const size_t q_words = w.q_words, b_q = w.b_q;
     const bool nee = w.nee;
-    const int parts = w.parts;
     char* base = (char*)c->d_wave;
     float4* ray0[2] = {(float4*)base, (float4*)(base + b_ray)};
     float4* ray1[2] = {(float4*)(base + 2 * b_ray), (float4*)(base + 3 * b_ray)};
@@ -454,31 +446,21 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
     HIP_TRY(c, hipGetLastError());
     if (stage_mark(c, PT_STAGE_GENERATE) != PT_OK) return PT_ERR_DEVICE;
 
-    const size_t lds_ext = (size_t)(L.lstk == 24 && !P.sc.wide8_root ? 24 : 16) * PT_BLOCK * 4;
+    const size_t lds_ext = (size_t)(L.lstk == 24 ? 24 : 16) * PT_BLOCK * 4;
     const size_t lds_shade = 15 * PT_KSPHERES * 4;
     // launchers: the extend stage's persistent grid (resident blocks, at most `blocks_per_cu` per CU) and the shade stage's one
-    // block per region, for the launch parameters Q (a whole bounce or one part of it) on stream s
-#define PT_EXT(COUNT, OCC, LSTK, FIRST, ...)                                                                      \
+    // block per region, for the launch parameters Q on stream s
+#define PT_EXT(COUNT, OCC, LSTK, FIRST)                                                                           \
         do {                                                                                                      \
             int per_cu = 0;                                                                                       \
-            if (allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST, ##__VA_ARGS__>, lds_ext) != hipSuccess) return hipErrorInvalidValue; \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK, FIRST, ##__VA_ARGS__>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
+            if (allow_lds(k_wf_extend<COUNT, OCC, LSTK, FIRST>, lds_ext) != hipSuccess) return hipErrorInvalidValue; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_wf_extend<COUNT, OCC, LSTK, FIRST>, PT_BLOCK, lds_ext) != hipSuccess || per_cu < 1) \
                 per_cu = 1;                                                                                       \
             per_cu = std::min(per_cu, blocks_per_cu);                                                             \
-            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST, ##__VA_ARGS__>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, (size_t)Q.wf.n_regions)), \
+            hipLaunchKernelGGL((k_wf_extend<COUNT, OCC, LSTK, FIRST>), dim3((unsigned)std::min<size_t>((size_t)per_cu * L.n_cu, (size_t)Q.wf.n_regions)), \
                                dim3(PT_BLOCK), lds_ext, s, Q);                                                    \
         } while (0)
     auto launch_extend = [&](const KParams& Q, bool first, hipStream_t s, int blocks_per_cu) -> hipError_t {
-        if (Q.sc.wide8_root) {   // the 8-wide tree, 16-entry LDS window; registers for 6 waves per SIMD (no spills) or, with PT_OPT_OCCUPANCY 8, for 8
-            if (L.occ >= 8) {
-                if (first) { if (L.count) PT_EXT(true, 8, 16, true, true); else PT_EXT(false, 8, 16, true, true); }
-                else { if (L.count) PT_EXT(true, 8, 16, false, true); else PT_EXT(false, 8, 16, false, true); }
-            } else {
-                if (first) { if (L.count) PT_EXT(true, 6, 16, true, true); else PT_EXT(false, 6, 16, true, true); }
-                else { if (L.count) PT_EXT(true, 6, 16, false, true); else PT_EXT(false, 6, 16, false, true); }
-            }
-            return hipGetLastError();
-        }
         if (first) {
             if (L.count) { if (L.lstk == 24) PT_EXT(true, 6, 24, true); else PT_EXT(true, 8, 16, true); }
             else { if (L.lstk == 24) PT_EXT(false, 6, 24, true); else PT_EXT(false, 8, 16, true); }
@@ -513,56 +495,8 @@ int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles) 
         Q.wf.ray0_out = ray0[g ^ 1]; Q.wf.ray1_out = ray1[g ^ 1]; Q.wf.mask_out = mask[g ^ 1]; Q.wf.cnt_out = cnt[g ^ 1];
     };
 
-    if (parts > 1) {
-        // ---- pipelined in parts (PT_OPT_WAVE_PARTS): the call's regions are cut into `parts` ranges; all extend launches go to
-        // the caller's stream in the order (bounce, part), all shade launches to a second stream in the same order, tied by
-        // events: shade(part, b) after extend(part, b), extend(part, b + 1) after shade(part, b).  While the waves of
-        // extend(part + 1, b) walk the tree — latency-bound, HBM nearly idle — the blocks of shade(part, b) stream their path
-        // records through the block slots the extend grid leaves free (PT_OPT_WAVE_BLOCKS < 8 per CU).  Same records, same
-        // arithmetic, same order inside every region: the images do not change.
-        if (!c->wave_stream) {
-            int prio_lo = 0, prio_hi = 0;
-            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->wave_stream, hipStreamNonBlocking, prio_hi));
-        }
-        const size_t n_ev = (size_t)parts * 4;   // [generation of the bounce][part][extend done / shade done]
-        while (c->wave_ev.size() < n_ev) {
-            hipEvent_t e = nullptr;
-            HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->wave_ev.push_back(e);
-        }
-        auto ev = [&](uint32_t b, int part, int kind) { return c->wave_ev[((size_t)(b & 1u) * parts + (size_t)part) * 2 + (size_t)kind]; };
-        const int ext_blocks = std::min(c->opt_wave_blocks, 7);   // at least one block slot per CU stays free for the shade stage
-        for (uint32_t b = 0; b < P.depth; b++) {
-            for (int part = 0; part < parts; part++) {
-                KParams Q = P;
-                set_bounce(Q, b);
-                const size_t r0 = n_regions * (size_t)part / (size_t)parts, r1 = n_regions * (size_t)(part + 1) / (size_t)parts;
-                Q.wf.region0 = (int)r0;
-                Q.wf.n_regions = (int)(r1 - r0);
-                Q.wf.queue = queues + ((size_t)b * parts + (size_t)part) * PT_SHARDS * PT_SHARD_STRIDE;
-                if (b > 0) HIP_TRY(c, hipStreamWaitEvent(st, ev(b - 1, part, 1), 0));        // this part's records of the last bounce are shaded
-                if (span_begin(c, st) != PT_OK) return PT_ERR_DEVICE;
-                HIP_TRY(c, launch_extend(Q, b == 0, st, ext_blocks));
-                if (span_end(c, PT_STAGE_EXTEND, st) != PT_OK) return PT_ERR_DEVICE;
-                HIP_TRY(c, hipEventRecord(ev(b, part, 0), st));
-                HIP_TRY(c, hipStreamWaitEvent(c->wave_stream, ev(b, part, 0), 0));
-                if (span_begin(c, c->wave_stream) != PT_OK) return PT_ERR_DEVICE;
-                HIP_TRY(c, launch_shade(Q, b == 0, c->wave_stream));
-                if (span_end(c, PT_STAGE_SHADE, c->wave_stream) != PT_OK) return PT_ERR_DEVICE;
-                HIP_TRY(c, hipEventRecord(ev(b, part, 1), c->wave_stream));
-            }
-        }
-        for (int part = 0; part < parts; part++)   // the fold (caller's stream) needs every part's last shade
-            HIP_TRY(c, hipStreamWaitEvent(st, ev(P.depth - 1, part, 1), 0));
-        if (stage_mark(c, PT_STAGE_NONE) != PT_OK) return PT_ERR_DEVICE;   // the launches above were timed one by one (spans)
-        return PT_OK;
-    }
-
     for (uint32_t b = 0; b < P.depth; b++) {
         set_bounce(P, b);
-        P.wf.region0 = 0;
-        P.wf.n_regions = (int)n_regions;
         P.wf.queue = queues + (size_t)b * PT_SHARDS * PT_SHARD_STRIDE;
         HIP_TRY(c, launch_extend(P, b == 0, st, c->opt_wave_blocks));
         if (stage_mark(c, PT_STAGE_EXTEND) != PT_OK) return PT_ERR_DEVICE;

@@ -14,9 +14,6 @@
 #define PT_TILE 8
 #define PT_MAX_TOP 1024       // most nodes the LDS copy of the top of the tree may hold
 #define PT_STACK_CAP 72       // deepest traversal stack (tree depth <= 64, SplitBVHBuilder MaxDepth)
-#define PT_STACK_CAP8 136     // ... of the 8-wide walk: a node pushes up to seven entries, and the bound the upload computes (every
-                              // child of every node on the deepest path hit) is what is checked against it; entries past the LDS
-                              // window live in private memory that is practically never touched
 #define PT_SHARDS 8           // work-queue counters (one per XCD worth of blocks)
 #define PT_SHARD_STRIDE 32    // uints between counters: one 128-byte line each
 #define PT_REGION 256         // stage-split pipeline: path-record slots per region (= one block)
@@ -35,7 +32,6 @@ struct KScene {
     int stack_n;   // LDS stack entries per lane
     int top_base;  // float4 index of the mirrored tree's root: 0 (binary) or wide_root
     int wide_root; // float4 index of the 4-wide quantised tree's root (= its node 0), 0 if absent
-    int wide8_root;// float4 index of the 8-wide tree's root (128-byte nodes), 0 if absent or not used by this launch
 };
 
 #define PT_KSPHERES 8   // spheres carried in the kernel-argument block (scalar loads); more -> global array
@@ -62,8 +58,7 @@ struct KWave {
     unsigned int* queues_all;     // k_wf_prepare: every bounce's counters, zeroed
     uint32_t queues_words;
     uint32_t cap;                 // slots per plane (regions * 256)
-    int n_regions;                // regions of THIS launch: the whole call's, or one part's when the call is pipelined in parts
-    int region0;                  // first region of this launch (0 unless pipelined)
+    int n_regions;
     uint32_t n_slots;             // (sample, pixel) slots of the call: work tiles * 64 (bounce 0 works on slots, not records)
     // PT_FLAG_NEE: the shadow-ray records a shade launch emits (region-compacted like the survivors), traced by another
     // extend launch and resolved by k_wf_resolve: s_ray0/s_ray1 as ray0/ray1, s_con = (contribution rgb, t_max), s_hit

@@ -57,9 +57,6 @@ struct Tree {
 
 struct Output {
     std::vector<float> bin, rec, wide;     // 16 floats per item
-    std::vector<float> wide8;              // 8-wide nodes, 32 floats each (two 64-byte halves), when asked for
-    size_t wide8_root_f4 = 0;              // float4 index of its root (a multiple of 8: one 128-byte line per node), 0 = none
-    uint32_t need8 = 0;                    // most stack entries its walk can hold at once (every child of every node on a path hit)
     uint32_t n_top_bin = 0, n_top_wide = 0;
     uint32_t depth_bin = 0, depth_wide = 0;
     uint64_t n_refs = 0, n_leaves = 0;
@@ -226,7 +223,7 @@ inline void bfs_then_dfs(size_t n, size_t max_top, KidsFn kids, std::vector<size
 
 struct WNode { Box3 cb[4]; int64_t child[4]; int n; };  // child >= 0: wide index, < 0: ~leaf index
 
-inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false, bool want8 = false) {
+inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false) {
     // reachable binary nodes, depth-first (also the record emission order)
     std::vector<size_t> reach;
     std::vector<int32_t> leaf_first(T.leaves.size(), -1);  // float4 index of a leaf's first record (relative)
@@ -390,106 +387,6 @@ inline void emit(const Tree& T, size_t max_top, Output& out, bool woop = false, 
             for (int k = 0; k < w.n; k++)
                 for (int a = 0; a < 3; a++) { cb[k].lo[a] = w.cb[k].lo[a]; cb[k].hi[a] = w.cb[k].hi[a]; }
             pt_encode_wide_node(cb, w.n, link, d);
-        }
-    }
-    out.wide8.clear();
-    out.wide8_root_f4 = 0;
-    out.need8 = 0;
-    if (!want8 || woop) return;
-    // ---- 8-wide collapse (PT_OPT_NODE_WIDTH 8): a node adopts up to EIGHT descendants, largest-area inner child first; its
-    // children are sorted along the node's longest axis and cut into two halves of <= 4, each encoded as a 4-wide item with
-    // its own grid (two tight grids instead of one loose one); the pair is one 128-byte line.
-    struct W8 { Box3 cb[8]; int64_t child[8]; int n; };
-    std::vector<W8> V;
-    {
-        auto grow8 = [&](size_t u) {
-            W8 w;
-            w.n = 0;
-            int64_t ref[8];
-            auto add = [&](size_t parent, int i) { w.cb[w.n] = T.nodes[parent].cb[i]; ref[w.n] = T.nodes[parent].child[i]; w.n++; };
-            add(u, 0); add(u, 1);
-            while (w.n < 8) {
-                int best = -1;
-                float ba = -1.f;
-                for (int k = 0; k < w.n; k++)
-                    if (ref[k] >= 0 && w.cb[k].area() > ba) { ba = w.cb[k].area(); best = k; }
-                if (best < 0) break;
-                const size_t v = (size_t)ref[best];
-                w.cb[best] = w.cb[w.n - 1];
-                ref[best] = ref[w.n - 1];
-                w.n--;
-                add(v, 0); add(v, 1);
-            }
-            // order along the longest axis of the node's box (by child-box centre), so that each half is spatially compact
-            Box3 nb; nb.reset();
-            for (int k = 0; k < w.n; k++) nb.grow(w.cb[k]);
-            int ax = 0;
-            for (int a2 = 1; a2 < 3; a2++) if (nb.hi[a2] - nb.lo[a2] > nb.hi[ax] - nb.lo[ax]) ax = a2;
-            int ord[8];
-            for (int k = 0; k < w.n; k++) ord[k] = k;
-            std::stable_sort(ord, ord + w.n, [&](int x, int y) { return w.cb[x].lo[ax] + w.cb[x].hi[ax] < w.cb[y].lo[ax] + w.cb[y].hi[ax]; });
-            W8 r;
-            r.n = w.n;
-            for (int k = 0; k < 8; k++) { r.child[k] = 0; }
-            for (int k = 0; k < w.n; k++) { r.cb[k] = w.cb[ord[k]]; r.child[k] = ref[ord[k]]; }
-            return r;
-        };
-        V.push_back(grow8(0));
-        for (size_t i = 0; i < V.size(); i++)
-            for (int k = 0; k < V[i].n; k++)
-                if (V[i].child[k] >= 0) {
-                    const size_t bin_node = (size_t)V[i].child[k];
-                    V[i].child[k] = (int64_t)V.size();
-                    V.push_back(grow8(bin_node));
-                }
-    }
-    // worst-case stack need: a node with n children pushes n - 1 before it descends (children come after their parent in V)
-    {
-        std::vector<uint32_t> need(V.size(), 0);
-        for (size_t i = V.size(); i-- > 0;) {
-            uint32_t below = 0;
-            for (int k = 0; k < V[i].n; k++) if (V[i].child[k] >= 0) below = std::max(below, need[(size_t)V[i].child[k]]);
-            need[i] = (uint32_t)(V[i].n - 1) + below;
-        }
-        out.need8 = need[0] + 1;   // + the sentinel
-    }
-    {
-        const size_t base8 = (wide_base + out.wide.size() / 4 + 7) / 8 * 8;   // 128-byte aligned (the buffer itself is 256-byte aligned)
-        out.wide8_root_f4 = base8;
-        std::vector<size_t> order, pos;
-        uint32_t n_top8 = 0;
-        auto kids = [&](size_t u, std::vector<size_t>& k) {
-            for (int i = 0; i < V[u].n; i++) if (V[u].child[i] >= 0) k.push_back((size_t)V[u].child[i]);
-        };
-        bfs_then_dfs(V.size(), max_top, kids, order, pos, n_top8);
-        out.wide8.assign(order.size() * 32, 0.f);
-        for (size_t oi = 0; oi < order.size(); oi++) {
-            const W8& w = V[order[oi]];
-            int32_t link[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int k = 0; k < w.n; k++)
-                if (w.child[k] >= 0) {
-                    link[k] = (int32_t)(base8 + 8 * pos[(size_t)w.child[k]]);
-                } else {
-                    const size_t li = (size_t)~(int32_t)w.child[k];
-                    const uint32_t n_rec = std::max<uint32_t>(T.leaves[li].count, 1u);
-                    link[k] = ~(int32_t)((rec_base + (size_t)leaf_first[li]) | (size_t)(std::min<uint32_t>(n_rec, 4u) - 1u));
-                }
-            const int na = w.n <= 4 ? w.n : (w.n + 1) / 2, nb2 = w.n - na;
-            PtBox cb[8];
-            for (int k = 0; k < w.n; k++)
-                for (int a2 = 0; a2 < 3; a2++) { cb[k].lo[a2] = w.cb[k].lo[a2]; cb[k].hi[a2] = w.cb[k].hi[a2]; }
-            float* d = &out.wide8[32 * oi];
-            pt_encode_wide_node(cb, na, link, d);
-            if (nb2 > 0) {
-                pt_encode_wide_node(cb + na, nb2, link + na, d + 16);
-            } else {   // an empty half: four inverted boxes (never hit), links = a copy of child 0's
-                const uint32_t lo_all = 0xffffffffu, hi_all = 0u;
-                d[16] = d[17] = d[18] = 0.f; d[19] = 1.f;
-                d[20] = i2f((int32_t)lo_all); d[21] = i2f((int32_t)lo_all); d[22] = i2f((int32_t)lo_all);
-                d[23] = i2f((int32_t)hi_all); d[24] = i2f((int32_t)hi_all); d[25] = i2f((int32_t)hi_all);
-                d[26] = d[27] = d[28] = d[29] = i2f(link[0]);
-                d[30] = 1.f; d[31] = 1.f;
-            }
         }
     }
 }

@@ -25,6 +25,15 @@ extern __shared__ float4 s_dyn[];
 #ifndef PT_NODE_STEP_HOOK
 #define PT_NODE_STEP_HOOK(sc, a, w)
 #endif
+// phase vote of the wide walk: a node step runs when  lanes at a node x VOTE_NODE >= lanes at a record x VOTE_REC.
+// Round 3 sweep (profiles/r03_vote_ab.txt; 800 k / 6.4 M scene, ms per step): 1:1 9.39-9.48 / 19.98, 2:3 9.36-9.50 / 20.09,
+// 1:2 (rounds 1-2) 9.36-9.43 / 20.22, 2:5 9.57-9.62 / 20.35, 1:3 9.53 / 20.42, 1:4 9.68-9.75 / 20.48 — the simple majority
+// is as fast as any on the cache-resident scene and 1.2 % ahead on the HBM-resident one, with record steps at 0.52 lane
+// use instead of 0.40 (node steps 0.67 instead of 0.75): the time does not follow either figure.
+#ifndef PT_WIDE_VOTE_NODE
+#define PT_WIDE_VOTE_NODE 1
+#define PT_WIDE_VOTE_REC 1
+#endif
 #ifndef PT_WALK_DECL_HOOK
 #define PT_WALK_DECL_HOOK()
 #define PT_NODE_END_HOOK(sc, cur)
@@ -48,26 +57,26 @@ __device__ __forceinline__ int pt_lane_fresh() {
     return l;
 }
 
-template <int LSTK, int CAP = PT_STACK_CAP>
+template <int LSTK>
 struct TravOverflow {
-    int e[LSTK < CAP ? CAP - LSTK : 1];
+    int e[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
 };
 
-template <int LSTK, int BLOCK, int CAP = PT_STACK_CAP>
+template <int LSTK, int BLOCK>
 struct TravStack {
     int base;  // WAVE-UNIFORM int index of lane 0's entry 0 inside s_dyn (the __shared__ symbol is
                // named in the accessors so that the accesses stay ds_read/ds_write: a stored
                // pointer makes hipcc merge the LDS and overflow paths into flat_load/flat_store)
     // the overflow array is a SEPARATE private object: as a member it drags the whole struct,
     // `base` included, into scratch memory (a scratch reload in front of every push)
-    int (&ovf)[LSTK < CAP ? CAP - LSTK : 1];
+    int (&ovf)[LSTK < PT_STACK_CAP ? PT_STACK_CAP - LSTK : 1];
     int lane_base;  // base + lane id.  Re-deriving the lane id at every access (v_mbcnt x2 + add) was the
                     // cheaper choice while ~120 SGPR spills ate the VGPR budget; with the kernel arguments
                     // read at use, one VGPR here saves ~12 VALU per node step (-1.4 % / -3.3 % at 8 / 6 waves)
     uint32_t n_ovf = 0;  // pushes that went past the LDS window (read by the instrumented kernels only)
-    __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK, CAP>& o) : base(b), ovf(o.e), lane_base(b + pt_lane_fresh()) {}
+    __device__ __forceinline__ TravStack(int b, TravOverflow<LSTK>& o) : base(b), ovf(o.e), lane_base(b + pt_lane_fresh()) {}
     __device__ __forceinline__ void put(int sp, int v) {
-        if (LSTK >= CAP || sp < LSTK) {
+        if (LSTK >= PT_STACK_CAP || sp < LSTK) {
             ((int*)s_dyn)[lane_base + sp * BLOCK] = v;
         } else {
             asm volatile("" : "+v"(v));
@@ -77,7 +86,7 @@ struct TravStack {
     }
     __device__ __forceinline__ int get(int sp) const {
         int v;
-        if (LSTK >= CAP || sp < LSTK) {
+        if (LSTK >= PT_STACK_CAP || sp < LSTK) {
             v = ((const int*)s_dyn)[lane_base + sp * BLOCK];
         } else {
             v = ovf[sp - LSTK];
@@ -373,8 +382,8 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         if (n_live == 0) break;
         if (DYN && 64 - n_live - n_dead >= batch) break;  // enough lanes wait for service
         const int n_node = __popcll(__ballot(is_node));
-        // a record step costs about half a node step: run whichever advances more lanes per instruction
-        const bool node_phase = n_node >= 2 * (n_live - n_node);
+        // the kind most live lanes are waiting for (weights: see PT_WIDE_VOTE_NODE)
+        const bool node_phase = PT_WIDE_VOTE_NODE * n_node >= PT_WIDE_VOTE_REC * (n_live - n_node);
         if (COUNT && pt_first_active_lane()) {  // one lane of those in the walk books the wave's iteration
             if (node_phase) { tc.it_node++; tc.act_node += n_node; }
             else { tc.it_rec++; tc.act_rec += n_live - n_node; }
@@ -481,130 +490,6 @@ __device__ __forceinline__ bool trav_run_wide(TravState& s, const KScene& sc, v3
         }
     }
     PT_WALK_EXIT_HOOK();
-    s.node = cur; s.sp = sp; s.h = h;
-    return cur == PT_SENTINEL;
-}
-
-// ---------------------------------------------------------------------------------------
-// 8-wide walk (PT_OPT_NODE_WIDTH 8): for scenes whose item buffer outgrows the caches.  Beyond L2 the memory system serves
-// REQUESTS, not bytes: dependent random gathers from a 1.2 GB table run at ~55 G/s for 64-byte items and ~47 G/s for
-// 128-byte ones (tools/ubench_gather, profiles/r03_ubench_gather.txt) — and two chains per lane are no faster than one,
-// so it is a request-rate ceiling, not latency.  An 8-wide node is ONE 128-byte line (two 64-byte halves in the 4-wide
-// format, each with its own quantisation grid; slots 0-3 / 4-7) and removes a third of the node visits.  In L2 the eight
-// 16-byte accesses per node cost 2.7x a 64-byte item, so cache-resident scenes keep the 4-wide tree.
-// Same records, same exact triangle test: the hits are the other walks'.
-__device__ __forceinline__ void wide_node_keys_raw(const WideNode& w, float idx, float idy, float idz, float oodx, float oody, float oodz,
-                                                   float t_max, uint32_t slot0, uint32_t* key) {
-    const float sx = w.sx * idx, sy = w.sy * idy, sz = w.sz * idz;
-    const float bx = fmaf(w.ox, idx, -oodx), by = fmaf(w.oy, idy, -oody), bz = fmaf(w.oz, idz, -oodz);
-    const bool px = idx >= 0.0f, py = idy >= 0.0f, pz = idz >= 0.0f;
-    const uint32_t nx = px ? w.qlx : w.qhx, fx = px ? w.qhx : w.qlx;
-    const uint32_t ny = py ? w.qly : w.qhy, fy = py ? w.qhy : w.qly;
-    const uint32_t nz = pz ? w.qlz : w.qhz, fz = pz ? w.qhz : w.qlz;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const pt_f2 tx = pt_fma2(pt_mk2((float)((nx >> (8 * k)) & 0xffu), (float)((fx >> (8 * k)) & 0xffu)), pt_mk2(sx, sx), pt_mk2(bx, bx));
-        const pt_f2 ty = pt_fma2(pt_mk2((float)((ny >> (8 * k)) & 0xffu), (float)((fy >> (8 * k)) & 0xffu)), pt_mk2(sy, sy), pt_mk2(by, by));
-        const pt_f2 tz = pt_fma2(pt_mk2((float)((nz >> (8 * k)) & 0xffu), (float)((fz >> (8 * k)) & 0xffu)), pt_mk2(sz, sz), pt_mk2(bz, bz));
-        const float tmin = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
-        const float tmax = fminf(fminf(fminf(tx.y, ty.y), tz.y), t_max);
-        key[k] = tmin <= tmax ? ((__float_as_uint(tmin) & 0x7ffffff8u) | (slot0 + (uint32_t)k)) : 0xffffffffu;
-    }
-}
-
-// link of slot (kk & 7) of an 8-wide node
-__device__ __forceinline__ int wide8_link(const WideNode& a, const WideNode& b, uint32_t kk) {
-    const int la = wide_link(a, kk), lb = wide_link(b, kk);
-    return (kk & 4u) ? lb : la;
-}
-
-template <bool COUNT, bool DYN, bool AHEAD, class STK>
-__device__ __forceinline__ bool trav_run_wide8(TravState& s, const KScene& sc, v3 o, v3 d, bool cull, STK& stk,
-                                               TravCount& tc, int n_dead, int batch) {
-    int cur = s.node, sp = s.sp;
-    Hit h = s.h;
-    const float idx = s.idx, idy = s.idy, idz = s.idz, oodx = s.oodx, oody = s.oody, oodz = s.oodz;
-    for (;;) {
-        const bool live = cur != PT_SENTINEL;
-        const bool is_node = live && cur >= 0;
-        const int n_live = __popcll(__ballot(live));
-        if (n_live == 0) break;
-        if (DYN && 64 - n_live - n_dead >= batch) break;
-        const int n_node = __popcll(__ballot(is_node));
-        // an 8-wide node step costs about four record steps
-        const bool node_phase = n_node >= 4 * (n_live - n_node) || n_node == n_live;
-        if (COUNT && pt_first_active_lane()) {
-            if (node_phase) { tc.it_node++; tc.act_node += n_node; }
-            else { tc.it_rec++; tc.act_rec += n_live - n_node; }
-        }
-        if (!live || is_node != node_phase) continue;
-        const int a = cur >= 0 ? cur : (~cur & ~3);
-        if (cur >= 0) {
-            const WideNode wa = wide_node_load(sc, a), wb = wide_node_load(sc, a + 4);
-            if (COUNT) tc.inner++;
-            uint32_t key[8];
-            wide_node_keys_raw(wa, idx, idy, idz, oodx, oody, oodz, h.t, 0u, key);
-            wide_node_keys_raw(wb, idx, idy, idz, oodx, oody, oodz, h.t, 4u, key + 4);
-#define PT_CE(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
-            PT_CE(0, 1) PT_CE(2, 3) PT_CE(4, 5) PT_CE(6, 7) PT_CE(0, 2) PT_CE(1, 3) PT_CE(4, 6) PT_CE(5, 7) PT_CE(1, 2) PT_CE(5, 6)
-            PT_CE(0, 4) PT_CE(3, 7) PT_CE(1, 5) PT_CE(2, 6) PT_CE(1, 4) PT_CE(3, 6) PT_CE(2, 4) PT_CE(3, 5) PT_CE(3, 4)
-#undef PT_CE
-            // far to near onto the stack; slots beyond the wave's largest hit count are skipped with one scalar branch
-#pragma unroll
-            for (int j = 7; j >= 1; j--) {
-                if (__ballot(key[j] != 0xffffffffu) == 0ull) continue;
-                if (key[j] != 0xffffffffu) { sp++; stk.put(sp, wide8_link(wa, wb, key[j])); }
-            }
-            if (key[0] != 0xffffffffu) {
-                cur = wide8_link(wa, wb, key[0]);
-            } else {
-                cur = stk.get(sp);
-                sp--;
-            }
-            if (COUNT && cur < 0) tc.leaves++;
-        } else {
-            // the record step of trav_run_wide<.., AHEAD> (exact Moller-Trumbore records; a leaf is finished inside the step)
-            float4 q0, q1, q2, x0, x1, x2;
-            const float4* p_ = sc.nodes + a;
-            if (AHEAD) {
-                q0 = p_[0]; q1 = p_[1]; q2 = p_[2];
-                x0 = x1 = x2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((~cur & 3) != 0) { x0 = p_[4]; x1 = p_[5]; x2 = p_[6]; }
-                asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                                  "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w),
-                                  "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w));
-            } else {
-                pt_ld4x3(p_, q0, q1, q2);
-            }
-            if (COUNT) tc.tris++;
-            const float t = pt_mt_intersect(V3(q0.x, q0.y, q0.z), V3(q1.x, q1.y, q1.z), V3(q2.x, q2.y, q2.z), o, d, cull);
-            const int id = __float_as_int(q0.w);
-            bool last = __float_as_int(q1.w) != 0;
-            if (t > 0.0f && (t < h.t || (t == h.t && h.tri != -1 && id < h.tri))) { h.t = t; h.tri = id; h.rec = a; }
-            int aa = a;
-            if (AHEAD && !last) {
-                aa += 4;
-                if (COUNT) tc.tris++;
-                const float t2 = pt_mt_intersect(V3(x0.x, x0.y, x0.z), V3(x1.x, x1.y, x1.z), V3(x2.x, x2.y, x2.z), o, d, cull);
-                const int id2 = __float_as_int(x0.w);
-                last = __float_as_int(x1.w) != 0;
-                if (t2 > 0.0f && (t2 < h.t || (t2 == h.t && h.tri != -1 && id2 < h.tri))) { h.t = t2; h.tri = id2; h.rec = aa; }
-            }
-            while (!last) {
-                aa += 4;
-                float4 r0, r1, r2;
-                pt_ld4x3(sc.nodes + aa, r0, r1, r2);
-                if (COUNT) tc.tris++;
-                const float t2 = pt_mt_intersect(V3(r0.x, r0.y, r0.z), V3(r1.x, r1.y, r1.z), V3(r2.x, r2.y, r2.z), o, d, cull);
-                const int id2 = __float_as_int(r0.w);
-                last = __float_as_int(r1.w) != 0;
-                if (t2 > 0.0f && (t2 < h.t || (t2 == h.t && h.tri != -1 && id2 < h.tri))) { h.t = t2; h.tri = id2; h.rec = aa; }
-            }
-            cur = stk.get(sp);
-            sp--;
-            if (COUNT && cur < 0 && cur != PT_SENTINEL) tc.leaves++;
-        }
-    }
     s.node = cur; s.sp = sp; s.h = h;
     return cur == PT_SENTINEL;
 }

@@ -31,18 +31,17 @@ static int tree_cost_impl(pt_ctx* c, double* node_visits, double* tri_tests);
 struct TreeState {
     float4 *d_nodes, *d_tris;
     bool records_woop, has_bvh;
-    uint64_t wide_root, n_wide, n_inner, n_refs, n_leaves, scene_bytes, wide8_root;
-    uint32_t wide_top_layout, wide_depth, n_top_layout, max_depth, wide8_need;
+    uint64_t wide_root, n_wide, n_inner, n_refs, n_leaves, scene_bytes;
+    uint32_t wide_top_layout, wide_depth, n_top_layout, max_depth;
     int32_t max_tri_id;
     float build_ms;
     static TreeState of(const pt_ctx* c) {
-        return {c->d_nodes, c->d_tris, c->records_woop, c->has_bvh, c->wide_root, c->n_wide, c->n_inner, c->n_refs, c->n_leaves, c->scene_bytes, c->wide8_root,
-                c->wide_top_layout, c->wide_depth, c->n_top_layout, c->max_depth, c->wide8_need, c->max_tri_id, c->build_ms};
+        return {c->d_nodes, c->d_tris, c->records_woop, c->has_bvh, c->wide_root, c->n_wide, c->n_inner, c->n_refs, c->n_leaves, c->scene_bytes,
+                c->wide_top_layout, c->wide_depth, c->n_top_layout, c->max_depth, c->max_tri_id, c->build_ms};
     }
     void restore(pt_ctx* c) const {
         c->d_nodes = d_nodes; c->d_tris = d_tris; c->records_woop = records_woop; c->has_bvh = has_bvh;
         c->wide_root = wide_root; c->n_wide = n_wide; c->n_inner = n_inner; c->n_refs = n_refs; c->n_leaves = n_leaves; c->scene_bytes = scene_bytes;
-        c->wide8_root = wide8_root; c->wide8_need = wide8_need;
         c->wide_top_layout = wide_top_layout; c->wide_depth = wide_depth; c->n_top_layout = n_top_layout; c->max_depth = max_depth;
         c->max_tri_id = max_tri_id; c->build_ms = build_ms;
     }
@@ -61,26 +60,6 @@ int stage_mark(pt_ctx* c, int kind) {
     HIP_TRY(c, hipEventRecord(c->stage_ev[c->stage_used], c->stream));
     c->stage_kind[c->stage_used] = kind;   // kind of the work that ENDS at this event
     c->stage_used++;
-    return PT_OK;
-}
-
-int span_begin(pt_ctx* c, hipStream_t s) {
-    if (!c->opt_timing) return PT_OK;
-    if (c->spans_used == c->spans.size()) {
-        pt_ctx::Span sp = {0, nullptr, nullptr};
-        HIP_TRY(c, hipEventCreate(&sp.e0));
-        HIP_TRY(c, hipEventCreate(&sp.e1));
-        c->spans.push_back(sp);
-    }
-    HIP_TRY(c, hipEventRecord(c->spans[c->spans_used].e0, s));
-    return PT_OK;
-}
-
-int span_end(pt_ctx* c, int kind, hipStream_t s) {
-    if (!c->opt_timing) return PT_OK;
-    HIP_TRY(c, hipEventRecord(c->spans[c->spans_used].e1, s));
-    c->spans[c->spans_used].kind = kind;
-    c->spans_used++;
     return PT_OK;
 }
 }  // namespace ptmi
@@ -144,9 +123,6 @@ int pt_destroy(pt_ctx* c) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     for (hipEvent_t e : c->stage_ev) (void)hipEventDestroy(e);
-    for (pt_ctx::Span& sp : c->spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
-    if (c->wave_stream) { (void)hipStreamSynchronize(c->wave_stream); (void)hipStreamDestroy(c->wave_stream); }
-    for (hipEvent_t e : c->wave_ev) (void)hipEventDestroy(e);
     for (pt_ctx::AutoPick& a : c->picks)
         for (hipEvent_t e : a.e) if (e) (void)hipEventDestroy(e);
     if (c->lights_ev) (void)hipEventDestroy(c->lights_ev);
@@ -216,14 +192,6 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             (option == PT_OPT_VOTE_NODE ? c->opt_vote_node : c->opt_vote_rec) = value;
             return PT_OK;
         case PT_OPT_OVERLAP: c->opt_overlap = value != 0; return PT_OK;
-        case PT_OPT_NODE_WIDTH:
-            if (value != 0 && value != 4 && value != 8) return fail(c, PT_ERR_INVALID, "pt_set_option: node width must be 4, 8 or 0 (8 when the items outgrow the Infinity Cache)");
-            c->opt_node_width = value;
-            return PT_OK;
-        case PT_OPT_WAVE_PARTS:
-            if (value < 1 || value > 16) return fail(c, PT_ERR_INVALID, "pt_set_option: wave parts must be 1..16");
-            c->opt_wave_parts = value;
-            return PT_OK;
         case PT_OPT_WAVE_BLOCKS:
             if (value < 1 || value > 8) return fail(c, PT_ERR_INVALID, "pt_set_option: wave blocks must be 1..8 per CU");
             c->opt_wave_blocks = value;
@@ -341,27 +309,20 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     if (rebuild == 1) return recluster();
     ptscene::refine(T, (uint32_t)c->opt_leaf_max);
     ptscene::Output O;
-    // the 8-wide tree beside the 4-wide one: asked for, or (auto) when the items alone outgrow the 256 MB Infinity Cache
-    const bool want8 = c->opt_tri_test == 0 && (c->opt_node_width == 8 || (c->opt_node_width == 0 && (T.nodes.size() + T.refs.size()) * 64 > (256u << 20)));
-    ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1, want8);
+    ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
     const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
-    const size_t w8_off = O.wide8_root_f4 * 16, w8b = O.wide8.size() * sizeof(float);   // 128-byte aligned, behind the 4-wide nodes
-    const size_t total_b = O.wide8_root_f4 ? w8_off + w8b : nb + tb + wb;
-    if (total_b / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
+    if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
     c->d_tris = nullptr;
     c->has_bvh = false;
-    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, total_b));
+    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb + wb));
     c->d_tris = c->d_nodes;  // one item buffer: links index it directly
     HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
-    if (O.wide8_root_f4) HIP_TRY(c, hipMemcpy((char*)c->d_nodes + w8_off, O.wide8.data(), w8b, hipMemcpyHostToDevice));
-    c->wide8_root = O.wide8_root_f4;
-    c->wide8_need = O.need8;
     c->records_woop = c->opt_tri_test == 1;
     c->wide_root = O.wide_root_f4;
     c->wide_top_layout = O.n_top_wide;
@@ -375,7 +336,7 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     c->n_refs = n_refs;
     c->n_leaves = n_leaves;
     c->max_depth = max_depth;
-    c->scene_bytes = total_b;
+    c->scene_bytes = nb + tb + wb;
     c->max_tri_id = max_id;
     c->has_bvh = true;
     c->build_ms = -1.f;   // an uploaded hierarchy: no device build stands behind this tree
@@ -733,14 +694,11 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     if (c->opt_timing) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         c->stage_used = 0;
-        c->spans_used = 0;
         if (stage_mark(c, PT_STAGE_NONE) != PT_OK) return PT_ERR_DEVICE;
     }
     const int lstk = c->opt_lstk ? c->opt_lstk : PT_STACK_CAP;   // any depth <= 64 works with every LDS window: deeper entries overflow
     P.sc.stack_n = lstk;
     P.sc.wide_root = (int)c->wide_root;
-    // the 8-wide tree serves the stage-split pipeline's extend stage only (the other kernels walk the 4-wide tree beside it)
-    P.sc.wide8_root = (wavefront && c->wide8_root && c->wide8_need <= (uint32_t)PT_STACK_CAP8 && c->opt_node_width != 4) ? (int)c->wide8_root : 0;
     P.sc.top_base = walk >= 2 ? (int)c->wide_root : 0;
     P.sc.n_top = c->has_bvh ? (int)std::min<uint32_t>((uint32_t)c->opt_top, walk >= 2 ? c->wide_top_layout : c->n_top_layout) : 0;
     if (walk >= 1) P.sc.n_top = 0;  // only the while-while walk reads the LDS mirror
@@ -960,13 +918,6 @@ int pt_get_stage_ms(pt_ctx* c, float* out, int n) {
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->stage_ev[i - 1], c->stage_ev[i]));
         const int k = c->stage_kind[i];
-        if (k >= 0 && k < n) out[k] += ms;
-    }
-    for (size_t i = 0; i < c->spans_used; i++) {   // launches timed one by one (they may have run side by side: the sum can exceed the call)
-        float ms = 0.f;
-        HIP_TRY(c, hipEventSynchronize(c->spans[i].e1));
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->spans[i].e0, c->spans[i].e1));
-        const int k = c->spans[i].kind;
         if (k >= 0 && k < n) out[k] += ms;
     }
     return PT_OK;

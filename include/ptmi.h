@@ -155,17 +155,6 @@ enum {
     PT_OPT_WAVE_BLOCKS = 19,  /* PT_KERNEL_WAVEFRONT, extend stage: resident 256-thread blocks per CU its persistent grid is
                                  sized for, 1..8 (default 8 = 8 waves per SIMD); fewer leave room for another
                                  context's launches on the same device                                 */
-    PT_OPT_NODE_WIDTH = 23,   /* the tree the stage-split pipeline's extend stage walks: 4 = the 4-wide tree of 64-byte nodes (what
-                                 every other kernel walks); 8 = an 8-wide tree of 128-byte nodes built BESIDE it at the next
-                                 pt_upload_bvh / pt_build_bvh (one line per node, a third fewer node visits: pays when the items
-                                 do not fit the caches, where the memory system serves requests rather than bytes; in L2 its
-                                 eight 16-byte accesses per node cost more than they save); 0 (default) = 8 when the items alone
-                                 exceed the 256 MB Infinity Cache, else 4.  Same closest hits (grazing cases as PT_OPT_REBUILD) */
-    PT_OPT_WAVE_PARTS = 22,   /* PT_KERNEL_WAVEFRONT: 1 = every stage of a bounce is ONE launch over all path records; n > 1 = the
-                                 call's records are cut into n ranges and pipelined: the shade launch of range k runs (on a
-                                 stream of the context's own) beside the extend launch of range k + 1, in the block slots the
-                                 extend grid leaves free (PT_OPT_WAVE_BLOCKS, at most 7 then).  Same images.  With
-                                 PT_OPT_TIMING the stage times are the sums of the launches' own durations (they overlap)  */
     PT_OPT_OVERLAP = 21,      /* 1 (default): the path kernel of a pt_render call (persistent / mega kernels) runs on a
                                  stream of the context's own, so that it can start while the PREVIOUS call's last paths
                                  drain; the fold into the accumulator stays on the caller's stream, in call order.  A

@@ -281,47 +281,7 @@ def test_big_scene_6400k_parity():
         ref, _, cnt = orc.render(bvh, sph, cam, p, 2, want_rgba=False)
         check(got, ref, "6400k device tree vs oracle over the host tree, 2 spp", 40)
         assert cnt["rays"] == W * H * 2 * p.depth
-        arbitrate(t, mesh, bvh, sph, cam, p, (4, 5), "6400k frames", 40)
-    finally:
-        t.close()
-
-
-@pytest.mark.parametrize("parts,blocks", [(2, 7), (4, 6), (3, 8)])
-def test_pipelined_parts_equal_the_plain_pipeline(parts, blocks):
-    """PT_OPT_WAVE_PARTS: the stage-split call cut into region ranges, shade(part) on a second stream beside
-    extend(part + 1) — same records, same arithmetic: bit-identical frames, accumulating over several calls, at sizes that
-    leave ragged last parts; the open scene (regions that run empty) too."""
-    t = g.PathTracer(0)
-    try:
-        t.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
-        for scene, sph, W, H, spp in (("cornell_dragon", g.reference_spheres(), 1280, 720, 4), ("dragon", None, 1001, 517, 3)):
-            _, bvh = bvh_of(scene)
-            cam = g.default_camera(W, H)
-            cam.dist = 18.0 * H / 1080
-            frames = []
-            for n_parts, n_blocks in ((1, 8), (parts, blocks)):
-                t.set_option(g.OPT_WAVE_PARTS, n_parts)
-                t.set_option(g.OPT_WAVE_BLOCKS, n_blocks)
-                t.upload_bvh(bvh)
-                t.upload_spheres(sph)
-                acc, rgba = t.alloc_frame(W, H)
-                for k in range(3):
-                    p = g.default_params(W, H)
-                    p.flags = g.FLAG_WRITE_RGBA
-                    p.frame, p.sample_index = k * spp, 1 + k * spp
-                    t.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
-                t.sync()
-                frames.append((acc.download(np.float32, (H, W, 3)), rgba.download(np.uint32, (H, W))))
-                acc.free()
-                rgba.free()
-            assert np.array_equal(frames[0][0], frames[1][0]) and np.array_equal(frames[0][1], frames[1][1])
-            assert frames[0][0].mean() > 0.01
-        # stage times of a pipelined call: per-launch spans
-        t.set_option(g.OPT_TIMING, 1)
-        acc, rgba = t.alloc_frame(W, H)
-        t.launch_kernel(acc.ptr, rgba.ptr, cam, g.default_params(W, H), spp)
-        t.sync()
-        st = t.stage_ms()
-        assert st["extend"] > 0 and st["shade"] > 0 and st["fold"] > 0
+        # frames 7, 8: bench.py's in-run parity frame of this scene, where one pixel of 2 073 600 differs from the oracle's walk
+        arbitrate(t, mesh, bvh, sph, cam, p, (4, 5, 7, 8), "6400k frames", 40)
     finally:
         t.close()

@@ -200,49 +200,3 @@ def test_wave_statistics_are_consistent():
                 assert w["act_rec"] == c["tris"]
         finally:
             t.close()
-
-
-@pytest.mark.parametrize("occ", [6, 8])
-def test_node_width_8_equals_oracle(occ):
-    """PT_OPT_NODE_WIDTH 8: the stage-split pipeline's extend stage over the 8-wide tree (128-byte nodes, two quantised halves),
-    built beside the 4-wide one at upload.  Same records, same exact triangle test: the oracle's frames (closed room, open
-    scene with ragged image, spatial-split tree, every material), and the persistent kernel on the same context — which walks
-    the 4-wide tree — renders the same frame."""
-    t = g.PathTracer(0)
-    try:
-        t.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
-        t.set_option(g.OPT_NODE_WIDTH, 8)
-        t.set_option(g.OPT_OCCUPANCY, occ)
-        for scene, sph, W, H, spp, mat in (("cornell", g.reference_spheres(), 320, 200, 4, g.MAT_DIFF), ("cornell_dragon", g.reference_spheres(), 960, 540, 2, g.MAT_METAL),
-                                           ("gto_sixteen", g.reference_spheres(), 640, 360, 3, g.MAT_REFR), ("dragon", None, 517, 293, 3, g.MAT_SPEC)):
-            _, bvh = bvh_of(scene)
-            cam = g.default_camera(W, H)
-            cam.dist = 18.0 * H / 1080
-            p = g.default_params(W, H, tri_mat=mat)
-            p.frame = 3
-            info0 = None
-            acc, _ = gpu_render(t, bvh, sph, cam, p, spp)
-            ref, _, _ = orc.render(bvh, sph, cam, p, spp, want_rgba=False)
-            n_diff = int(np.any(acc != ref, axis=-1).sum())
-            print(f"8-wide {scene}: differing pixels {n_diff} of {W * H}; {t.scene_info()}")
-            assert l2(acc, ref) < 1e-3 and n_diff <= 2
-            t.set_option(g.OPT_KERNEL, g.KERNEL_PERSISTENT)
-            try:
-                acc4, _ = gpu_render(t, None, sph, cam, p, spp)
-            finally:
-                t.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
-            assert int(np.any(acc4 != acc, axis=-1).sum()) <= 2
-        # instrumented: the 8-wide tree visits fewer nodes than the 4-wide one on the same scene
-        _, bvh = bvh_of("cornell_dragon")
-        cam, p = g.default_camera(640, 360), g.default_params(640, 360)
-        counts = {}
-        for width in (8, 4):
-            t.set_option(g.OPT_NODE_WIDTH, width)
-            t.set_option(g.OPT_COUNTERS, 1)
-            gpu_render(t, bvh, g.reference_spheres(), cam, p, 2)
-            counts[width] = t.counters()
-            t.set_option(g.OPT_COUNTERS, 0)
-        print("8-wide vs 4-wide counters", counts)
-        assert counts[8]["rays"] == counts[4]["rays"] and counts[8]["inner"] < 0.8 * counts[4]["inner"]
-    finally:
-        t.close()

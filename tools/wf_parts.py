@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""PT_OPT_WAVE_PARTS x PT_OPT_WAVE_BLOCKS on the bench step (or --scene ...): wall ms per step and the frame's crc.
-Usage: wf_parts.py [--scene cornell_dragon_800k] [--spp 16] [--device-build] parts:blocks ..."""
+"""The bench step (or --scene ...) of the stage-split pipeline under a few settings: wall ms per step, the frame's crc, per-ray
+counters.  Usage: wf_parts.py [--scene cornell_dragon_800k] [--spp 16] [--device-build | --keep | --no-splits] parts:blocks ...
+`parts` > 1 (shade of one region range beside the extend of the next, two streams) and --node-width 8 drive experiments that were
+measured and removed (round 3: profiles/r03_wf_parts.txt, r03_wide8_ab.txt; code in commit aada2a3 and its parent): with this
+library they are refused; 1:8 is the product."""
 import sys, time, zlib, os
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -24,8 +27,8 @@ W, H = 1920, 1080
 pt = g.PathTracer(0)
 pt.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
 mesh = g.scene_mesh(scene)
-if node_width is not None:
-    pt.set_option(g.OPT_NODE_WIDTH, node_width)
+if node_width is not None:   # the 8-wide experiment (commit aada2a3: profiles/r03_wide8_ab.txt); the option is gone with it
+    pt.set_option(23, node_width)
 if occ is not None:
     pt.set_option(g.OPT_OCCUPANCY, occ)
 t0 = time.perf_counter()
@@ -47,7 +50,9 @@ def run(n, first=0):
         pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
 for rnd in range(2):
     for parts, blocks in cfgs:
-        pt.set_option(g.OPT_WAVE_PARTS, parts); pt.set_option(g.OPT_WAVE_BLOCKS, blocks)
+        if parts > 1:
+            pt.set_option(22, parts)   # PT_OPT_WAVE_PARTS of the experiment build
+        pt.set_option(g.OPT_WAVE_BLOCKS, blocks)
         acc.zero(); run(3); pt.sync()
         t0 = time.perf_counter(); run(10, 3); pt.sync()
         dt = (time.perf_counter() - t0) / 10 * 1e3
