@@ -379,10 +379,10 @@ def main():
         return dt
 
     # ------------------------------------------------------------------ the timed region
-    # Library warm start, in front of the W warm-up steps and whatever W is: PT_KERNEL_AUTO's two trial calls and its decision
+    # Library warm start, in front of the W warm-up steps and whatever W is: PT_KERNEL_AUTO's four trial calls and its decision
     # (per configuration: image, spp, partition), and the buffers either stage layout allocates on first use.  The first
     # warm-up step restarts the running mean (sample_index 1), so nothing of these calls is left in the frame.
-    for k in range(4):
+    for k in range(6):
         step(k)
     torch.cuda.synchronize()
     for k in range(a.warmup):
@@ -437,9 +437,9 @@ def main():
         return round(rays_per_step / a.spp * spp * n_steps / seconds / 1e6, 1)
 
     def settle(params=base, spp=a.spp):
-        """untimed calls in front of a side measurement: PT_KERNEL_AUTO's two trial calls, its decision, and the
+        """untimed calls in front of a side measurement: PT_KERNEL_AUTO's four trial calls, its decision, and the
         buffers either stage layout allocates on first use"""
-        for k in range(4):
+        for k in range(6):
             step(k, params, spp=spp)
         torch.cuda.synchronize()
 

@@ -75,16 +75,17 @@ struct pt_ctx {
     int opt_wave_batch = 16;     // extend kernel: finished lanes that make a wave leave the walk to write hits / refill
     int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
     // PT_KERNEL_AUTO: which stage layout is faster depends on the workload (long paths and many samples per call:
-    // the stage-split pipeline; short paths or few samples: the persistent kernel), so the first two calls of a
-    // configuration time one each (HIP events on the stream, buffers allocated before the timed span) and the following
-    // ones run the faster.  A small table of configurations (least recently used replaced): a context that cycles through
+    // the stage-split pipeline; short paths or few samples: the persistent kernel), so the first FOUR calls of a
+    // configuration are timed trials, two per layout, alternating (HIP events on the stream, buffers allocated before the
+    // timed span; the faster trial of each layout counts) and the following ones run the faster layout.  A small table of configurations (least recently used replaced): a context that cycles through
     // a few configurations — the partitions of a tile split, two image sizes — keeps every decision.
     struct AutoPick {
+        static constexpr int TRIALS = 4, PENDING = 4, DECIDED = 5;
         uint64_t key = 0;        // what the choice was made for: image, spp, depth, partition shape, scene generation, material, flags
-        int phase = 0;           // 0: time the persistent kernel  1: time the pipeline  2: events pending  3: decided
+        int phase = 0;           // 0..3: this call is timed trial `phase` (even: persistent kernel, odd: pipeline)  4: events pending  5: decided
         int choice = PT_KERNEL_PERSISTENT;
-        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
-        float ms[2] = {0.f, 0.f};
+        hipEvent_t e[2 * TRIALS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start / end of every trial
+        float ms[2] = {0.f, 0.f};   // the faster of each layout's two trials (a context's very first launch is slow: code upload)
         uint64_t used = 0;       // tick of the last pt_render that looked this entry up
     };
     static constexpr int N_PICKS = 8;

@@ -49,6 +49,35 @@ struct TreeState {
 }  // namespace ptmi
 
 namespace ptmi {
+// PT_KERNEL_AUTO: reads the trials' events once they have all completed (wait = false: only if that needs no waiting) and decides
+static bool auto_decide(pt_ctx* c, pt_ctx::AutoPick& a, bool wait) {
+    using AP = pt_ctx::AutoPick;
+    if (a.phase != AP::PENDING) return a.phase == AP::DECIDED;
+    for (int t = 0; t < AP::TRIALS; t++) {
+        const hipError_t e = wait ? hipEventSynchronize(a.e[2 * t + 1]) : hipEventQuery(a.e[2 * t + 1]);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // hipErrorNotReady is not an error of the call
+    }
+    float best[2] = {3.0e38f, 3.0e38f};
+    bool ok = true;
+    for (int t = 0; t < AP::TRIALS; t++) {
+        float ms = 0.f;
+        ok = ok && hipEventElapsedTime(&ms, a.e[2 * t], a.e[2 * t + 1]) == hipSuccess;
+        best[t & 1] = std::min(best[t & 1], ms);
+    }
+    a.ms[0] = best[0]; a.ms[1] = best[1];
+    a.choice = ok && a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;
+    a.phase = AP::DECIDED;
+    bool wave_wanted = false;   // by any remembered configuration
+    for (const AP& o : c->picks)
+        if (o.key && (o.phase < AP::DECIDED || o.choice == PT_KERNEL_WAVEFRONT)) wave_wanted = true;
+    if (!wave_wanted && c->d_wave) {   // the pipeline's path records (3 GB at 1080p x 16 spp) are not needed; the trials that used them are done
+        (void)hipFree(c->d_wave);
+        c->d_wave = nullptr;
+        c->wave_bytes = 0;
+    }
+    return true;
+}
+
 int stage_mark(pt_ctx* c, int kind) {
     if (!c->opt_timing) return PT_OK;
     if (c->stage_used == c->stage_ev.size()) {
@@ -588,7 +617,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
             if (slot < 0) {
                 slot = lru;
                 pt_ctx::AutoPick& n = c->picks[slot];
-                if (n.phase == 1 || n.phase == 2)   // a trial of the configuration it held may still be in flight: its events must be idle
+                if (n.phase > 0 && n.phase < pt_ctx::AutoPick::DECIDED)   // trials of the configuration it held may still be in flight: its events must be idle
                     for (hipEvent_t e : n.e) if (e) (void)hipEventSynchronize(e);
                 n.key = key; n.phase = 0; n.choice = PT_KERNEL_PERSISTENT; n.ms[0] = n.ms[1] = 0.f;
             }
@@ -596,31 +625,15 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
             a.used = ++c->pick_tick;
             c->pick_last = slot;
             pick = &a;
-            if (a.phase == 2) {   // both trials are queued: decide once their events have completed, never wait for them
-                if (hipEventQuery(a.e[3]) == hipSuccess && hipEventQuery(a.e[1]) == hipSuccess) {
-                    const bool ok = hipEventElapsedTime(&a.ms[0], a.e[0], a.e[1]) == hipSuccess && hipEventElapsedTime(&a.ms[1], a.e[2], a.e[3]) == hipSuccess;
-                    a.choice = ok && a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;
-                    a.phase = 3;
-                    bool wave_wanted = false;   // by any remembered configuration
-                    for (const pt_ctx::AutoPick& o : c->picks)
-                        if (o.key && (o.phase == 1 || o.phase == 2 || (o.phase == 3 && o.choice == PT_KERNEL_WAVEFRONT))) wave_wanted = true;
-                    if (!wave_wanted && c->d_wave) {   // the pipeline's path records (3 GB at 1080p x 16 spp) are not needed; the trial that used them is done
-                        (void)hipFree(c->d_wave);
-                        c->d_wave = nullptr;
-                        c->wave_bytes = 0;
-                    }
-                } else {
-                    (void)hipGetLastError();   // hipErrorNotReady is not an error of this call
-                }
-            }
-            if (a.phase < 2) {
+            (void)auto_decide(c, a, false);   // all trials queued: decide once their events have completed, never wait for them
+            if (a.phase < pt_ctx::AutoPick::TRIALS) {
                 for (hipEvent_t& e : a.e)
                     if (!e) HIP_TRY(c, hipEventCreate(&e));
                 probe = a.phase;
-                kernel = probe == 0 ? PT_KERNEL_PERSISTENT : PT_KERNEL_WAVEFRONT;
+                kernel = (probe & 1) ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;
                 a.phase++;
             } else {
-                kernel = a.phase == 3 ? a.choice : PT_KERNEL_PERSISTENT;
+                kernel = a.phase == pt_ctx::AutoPick::DECIDED ? a.choice : PT_KERNEL_PERSISTENT;
             }
         }
     }
@@ -642,7 +655,14 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     // counters, so it can start while the previous call's last paths drain (the tail of a call is as long as its
     // longest path: ~15 % of a one-sample 1080p call); instrumented, timed and trial calls run in line
     pt_ctx::Side* sd = nullptr;
-    if (c->opt_overlap && !wavefront && !c->opt_counters && !c->opt_timing && probe < 0) {
+    // ... unless the caller's stream is idle: a host that syncs before every launch (BasicScene.cpp:395) leaves nothing to overlap
+    // with, and in line the call is two launches shorter (no cross-stream events; one sample folds inside the path kernel)
+    bool caller_idle = false;
+    if (c->opt_overlap && !wavefront) {
+        caller_idle = hipStreamQuery(c->stream) == hipSuccess;
+        if (!caller_idle) (void)hipGetLastError();   // hipErrorNotReady is not an error of this call
+    }
+    if (c->opt_overlap && !wavefront && !c->opt_counters && !c->opt_timing && probe < 0 && !caller_idle) {
         sd = &c->side[c->side_next];
         c->side_next ^= 1;
         if (!sd->stream) {
@@ -686,7 +706,7 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
     }
 
     if (c->opt_counters) HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    if (probe == 1) {   // the pipeline's trial: its path records are allocated BEFORE the timed span
+    if (probe >= 0 && (probe & 1)) {   // a trial of the pipeline: its path records are allocated BEFORE the timed span
         const int rc = wave_reserve(c, P, work_tiles);
         if (rc != PT_OK) return rc;
     }
@@ -854,12 +874,7 @@ int pt_auto_choice(pt_ctx* c, int* kernel, float* ms_persistent, float* ms_wavef
     if (ms_wavefront) *ms_wavefront = 0.f;
     if (c->pick_last < 0) return PT_OK;
     pt_ctx::AutoPick& a = c->picks[c->pick_last];
-    if (a.phase == 2 && hipEventSynchronize(a.e[1]) == hipSuccess && hipEventSynchronize(a.e[3]) == hipSuccess &&
-        hipEventElapsedTime(&a.ms[0], a.e[0], a.e[1]) == hipSuccess && hipEventElapsedTime(&a.ms[1], a.e[2], a.e[3]) == hipSuccess) {
-        a.choice = a.ms[1] < a.ms[0] ? PT_KERNEL_WAVEFRONT : PT_KERNEL_PERSISTENT;   // the caller asks: waiting is fine here
-        a.phase = 3;
-    }
-    if (a.phase >= 3) *kernel = a.choice;
+    if (auto_decide(c, a, true)) *kernel = a.choice;   // the caller asks: waiting for the trials is fine here
     if (ms_persistent) *ms_persistent = a.ms[0];
     if (ms_wavefront) *ms_wavefront = a.ms[1];
     return PT_OK;

@@ -111,9 +111,9 @@ enum {
 enum {
     PT_KERNEL_AUTO = 0,      /* PT_KERNEL_PERSISTENT or PT_KERNEL_WAVEFRONT, whichever is faster for the
                                 configuration (image, samples per call, depth, partition shape, scene, material,
-                                flags): the first two pt_render calls of a configuration time one layout each
-                                with HIP events (buffers are allocated before the timed span) and the following
-                                ones run the faster; the images are the same.  The decision never blocks the
+                                flags): the first four pt_render calls of a configuration are timed trials, two per
+                                layout (HIP events; buffers are allocated before the timed span; the faster trial
+                                of each layout counts) and the following ones run the faster; the images are the same.  The decision never blocks the
                                 host: while a trial's events are still pending, calls run the persistent kernel.
                                 The library remembers the last 8 configurations.  pt_auto_choice reports it   */
     PT_KERNEL_MEGA_BVH2 = 1, /* one lane per pixel, one wave per 8x8 tile, bounce by bounce      */
@@ -157,9 +157,10 @@ enum {
                                  context's launches on the same device                                 */
     PT_OPT_OVERLAP = 21,      /* 1 (default): the path kernel of a pt_render call (persistent / mega kernels) runs on a
                                  stream of the context's own, so that it can start while the PREVIOUS call's last paths
-                                 drain; the fold into the accumulator stays on the caller's stream, in call order.  A
-                                 host that syncs before every launch (as BasicScene.cpp:395 does) sees no difference;
-                                 0 = everything on the caller's stream                                          */
+                                 drain; the fold into the accumulator stays on the caller's stream, in call order.  When
+                                 the caller's stream is idle at the call — a host that syncs before every launch, as
+                                 BasicScene.cpp:395 does — the call runs in line on the caller's stream instead;
+                                 0 = always in line                                                             */
     PT_OPT_BUILD_ALGO = 16,   /* pt_build_bvh: 1 (default) = PLOC (locally-ordered clustering over Morton order:
                                  a tree as good as the host SAH/SBVH builder's, ~6.5 ms for 800 k triangles;
                                  degenerate input falls back to 0), 0 = LBVH (Karras hierarchy: 1.8 ms, a

@@ -14,7 +14,7 @@ for name in ("cornell_dragon_2700k","cornell_dragon_6400k"):
                 for f in range(n):
                     p=g.default_params(W,H); p.frame,p.sample_index=f*16,1+f*16; p.flags=g.FLAG_WRITE_RGBA
                     pt.launch_kernel(acc.ptr,rgba.ptr,cam,p,16)
-            run(4); pt.sync()
+            run(6); pt.sync()
             t0=time.perf_counter(); run(5); pt.sync()
             dt=(time.perf_counter()-t0)/5*1e3
             print(name, kern, f"build {ms:.1f} ms, {info['device_bytes']/2**20:.0f} MB, {dt:.2f} ms/step = {W*H*64/dt/1e3:.0f} Mrays/s", pt.auto_choice(), flush=True)

@@ -34,7 +34,7 @@ def timed(pt, spp, acc, rgba, cam, frames):
             p.frame, p.sample_index = (first + i) * spp, 1 + (first + i) * spp
             pt.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
     acc.zero()
-    run(3, 0)   # PT_KERNEL_AUTO decides in its first calls
+    run(6, 0)   # PT_KERNEL_AUTO decides in its first calls (four timed trials)
     pt.sync()
     t0 = time.perf_counter()
     run(frames, 3)
