@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --cpu-frames 0 --no-cpu-reference --no-extra $*"
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --cpu-frames 0 --no-cpu-reference --no-extra --no-pmc $*"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 echo "trace done"

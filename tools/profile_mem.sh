@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --cpu-frames 0 --no-cpu-reference --no-extra $*"
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --cpu-frames 0 --no-cpu-reference --no-extra --no-pmc $*"
 i=0
 for SET in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" \
            "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
