@@ -161,13 +161,28 @@ def gather_bound(table_bytes):
     return json.loads(line[-1]) if out.returncode == 0 and line else None
 
 
+def pmc_values(directory, counter, kernel_family):
+    """Per-dispatch values of `counter` for the non-instrumented instantiations of one kernel family (k_wf_extend<false, ...>,
+    k_trace_persist_bvh2<false, ...>, plain names) from the counter_collection.csv files rocprofv3 --pmc wrote under `directory`."""
+    import csv
+    vals = []
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            head = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if row["Counter_Name"] != counter or head.split("<")[0] != kernel_family:
+                continue
+            if "<" in head and head.split("<")[-1].split(",")[0].strip() == "true":   # instrumented (COUNT) instantiation
+                continue
+            vals.append(float(row["Counter_Value"]))
+    return vals
+
+
 def pmc_live(kernel_family, extra_args, timeout=240):
     """HBM-side traffic per launch of one kernel family, measured NOW for the running sources: this script is run again as a
     CHILD under `rocprofv3 --pmc <counter>` (one pass per counter: FETCH_SIZE and WRITE_SIZE do not fit one pass,
     MI355X_MICROARCH.md "rocprofv3 PMC slots"), timed steps only.  FETCH_SIZE is raw (TCC_EA0_RDREQ x 64 B: exact for 64-byte
     gathers, HALF the bytes of a wide coalesced stream on gfx950 — the x2 figure is kept beside it); WRITE_SIZE is exact.
     Returns None when rocprofv3 is not there or a pass fails (the committed profiles/ figure is quoted instead)."""
-    import csv
     import shutil
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
@@ -185,15 +200,7 @@ def pmc_live(kernel_family, extra_args, timeout=240):
                 r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             except Exception:
                 return None
-            vals = []
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    head = row["Kernel_Name"].split("(")[0].replace("void ", "")
-                    if row["Counter_Name"] != counter or head.split("<")[0] != kernel_family:
-                        continue
-                    if "<" in head and head.split("<")[-1].split(",")[0].strip() == "true":   # instrumented instantiation
-                        continue
-                    vals.append(float(row["Counter_Value"]))
+            vals = pmc_values(d, counter, kernel_family)
             if r.returncode != 0 or not vals:
                 return None
             out[counter] = (sum(vals) / len(vals) * 1024.0, len(vals))
@@ -615,6 +622,23 @@ def main():
                              "n_diff": int(np.any(got != ref_acc, axis=-1).sum()), "pixels": W * H,
                              "max_abs": float(np.abs(diff).max()),
                              "what": f"GPU accumulator after {a.cpu_frames} timed-configuration step(s) vs oracle/pt_oracle.c, same seeds"}
+            # ... and of the two other triangle materials the line quotes rates for (configs[2]: metal, specular), at 2 spp
+            if not a.no_extra:
+                import orc
+                for name, m in (("metal", g.MAT_METAL), ("spec", g.MAT_SPEC)):
+                    if m == mat:
+                        continue
+                    pm = g.Params.from_buffer_copy(base)
+                    pm.part_count, pm.part_index = 1, 0
+                    pm.tri_mat, pm.frame, pm.sample_index = m, 3, 1
+                    acc_m = torch.zeros_like(accum)
+                    pt.launch_kernel(acc_m.data_ptr(), rgba.data_ptr(), cam, pm, 2)
+                    torch.cuda.synchronize()
+                    got_m = acc_m[:H].cpu().numpy()
+                    ref_m, _, _ = orc.render(bvh if bvh is not None else g.Bvh(mesh), sph, cam, pm, spp=2, want_rgba=False)
+                    d_m = got_m.astype(np.float64) - ref_m
+                    out[f"parity_{name}"] = {"l2": float(np.sqrt(np.mean(np.sum(d_m ** 2, axis=-1)))), "n_diff": int(np.any(got_m != ref_m, axis=-1).sum()),
+                                             "pixels": W * H, "what": f"2 spp, triangle material {name}, vs the oracle"}
             if dom:
                 # SURVEY 8(d)'s figure, kept beside: ALGORITHMIC bytes of the REFERENCE layout (64 B per binary node, 48 B per
                 # triangle, 16 B per leaf, 4 B per hit, 44 B per sphere, 28 B per pixel-sample), counted by the oracle on the

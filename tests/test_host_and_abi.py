@@ -3,6 +3,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -226,3 +227,23 @@ def test_bench_and_entry_points_parse():
         ast.parse(open(os.path.join(root, rel)).read(), rel)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+
+
+def test_bench_pmc_csv_parsing(tmp_path):
+    """bench.py's reader of rocprofv3 --pmc output: per-dispatch counter values of one kernel family, instrumented
+    instantiations (first template argument true) and other kernels left out."""
+    sys.path.insert(0, ROOT)
+    import bench
+    d = tmp_path / "FETCH_SIZE" / "host" / "1234"
+    d.mkdir(parents=True)
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value",
+            '1,1,4,"void k_wf_extend<false, 8, 16, true>(KParams)",FETCH_SIZE,1000.0',
+            '2,2,4,"void k_wf_extend<false, 8, 16, false>(KParams)",FETCH_SIZE,3000.0',
+            '3,3,4,"void k_wf_extend<true, 8, 16, false>(KParams)",FETCH_SIZE,999999.0',
+            '4,4,4,"void k_wf_shade<false, false, false, true>(KParams)",FETCH_SIZE,500.0',
+            '5,5,4,"k_fold_samples(KParams)",FETCH_SIZE,7.0',
+            '6,6,4,"void k_wf_extend<false, 8, 16, false>(KParams)",WRITE_SIZE,11.0']
+    (d / "1234_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    assert bench.pmc_values(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE", "k_wf_extend") == [1000.0, 3000.0]
+    assert bench.pmc_values(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE", "k_fold_samples") == [7.0]
+    assert bench.pmc_values(str(tmp_path / "FETCH_SIZE"), "WRITE_SIZE", "k_wf_shade") == []
