@@ -225,6 +225,11 @@ def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))
+    # stdout carries exactly ONE line, rank 0's JSON: whatever libraries print on the way (RCCL's version banner, gloo's
+    # connection notes) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,7 +403,7 @@ def main():
     dt = timed(a.steps, a.warmup, per_step=step_ms)
     if a.pmc_child:   # the run rocprofv3 wraps (pmc_live): nothing but the timed steps
         if rank == 0:
-            print(json.dumps({"pmc_child": True, "ms_per_step": round(dt / a.steps * 1e3, 4)}))
+            os.write(json_fd, (json.dumps({"pmc_child": True, "ms_per_step": round(dt / a.steps * 1e3, 4)}) + "\n").encode())
         pt.close()
         return
 
@@ -782,7 +787,8 @@ def main():
             out["big_scene"] = {"error": str(e)[:200], "where": traceback.format_exc().strip().splitlines()[-3:]}
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
