@@ -295,14 +295,20 @@ def main():
     if a.device_build:
         pt.build_bvh(mesh)
     else:
-        # the reference's flow: hierarchy built on the host (SBVH port), flattened, uploaded.  PT_OPT_REBUILD 2: the upload keeps
-        # the caller's triangles and whichever hierarchy — the caller's or the device's re-clustered one — is cheaper to walk
+        # the reference's flow: hierarchy built on the host (SBVH port), flattened, uploaded.  PT_OPT_OPTIMIZE 2: the upload first
+        # re-inserts every node of the caller's hierarchy where the area cost grows least (two passes, on the host, outside every
+        # timed region — the reference's own builder takes longer); PT_OPT_REBUILD 2: it also re-clusters the triangles on the
+        # device and keeps whichever hierarchy is cheaper to walk
+        pt.set_option(g.OPT_OPTIMIZE, 0 if a.keep_hierarchy else 2)
         pt.set_option(g.OPT_REBUILD, 0 if a.keep_hierarchy else 2)
+        t_up = time.perf_counter()
         pt.upload_bvh(bvh)
+        t_up = time.perf_counter() - t_up
         pt.set_option(g.OPT_REBUILD, 0)
-        tree_note = ("host SBVH hierarchy, uploaded (PT_OPT_REBUILD 0)" if a.keep_hierarchy else
-                     "host SBVH hierarchy uploaded with PT_OPT_REBUILD 2: kept " +
-                     ("the device's re-clustered tree" if pt.last_build_ms() > 0 else "the uploaded hierarchy"))
+        pt.set_option(g.OPT_OPTIMIZE, 0)
+        tree_note = ("host SBVH hierarchy, uploaded as built (PT_OPT_OPTIMIZE 0, PT_OPT_REBUILD 0)" if a.keep_hierarchy else
+                     f"host SBVH hierarchy uploaded with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2 ({t_up:.1f} s): kept " +
+                     ("the device's re-clustered tree" if pt.last_build_ms() > 0 else "the uploaded hierarchy, optimised"))
     pt.upload_spheres(sph)
     info = pt.scene_info()
     try:
@@ -674,11 +680,17 @@ def main():
         # side measurement: the same workload over a tree built ON the device
         # (pt_build_bvh); done last, it replaces the scene of this context
         n_x = max(5, a.steps // 5)
-        if bvh is not None and not a.keep_hierarchy:   # the uploaded hierarchy itself, whatever PT_OPT_REBUILD 2 decided
+        if bvh is not None and not a.keep_hierarchy:   # the uploaded hierarchy AS BUILT (no optimisation, no re-clustering) ...
             pt.upload_bvh(bvh)
             settle()
             out["mrays_per_s_uploaded_hierarchy"] = rate(n_x, timed(n_x, 1))
             out["area_cost_node_visits_uploaded_hierarchy"] = round(pt.tree_cost()[0], 3)
+            pt.set_option(g.OPT_REBUILD, 1)            # ... and the device's re-clustered tree (PLOC), whatever the upload kept
+            pt.upload_bvh(bvh)
+            pt.set_option(g.OPT_REBUILD, 0)
+            settle()
+            out["mrays_per_s_reclustered_tree"] = rate(n_x, timed(n_x, 1))
+            out["area_cost_node_visits_reclustered_tree"] = round(pt.tree_cost()[0], 3)
         build_ms = min(pt.build_bvh(mesh) for _ in range(3))
         settle()
         out["device_bvh_build_ms"] = round(build_ms, 2)          # PLOC (the default PT_OPT_BUILD_ALGO)

@@ -61,12 +61,13 @@ class Counters(C.Structure):
 class BuildParams(C.Structure):
     _fields_ = [("max_leaf_size", C.c_int32), ("min_leaf_size", C.c_int32), ("max_depth", C.c_int32),
                 ("n_bins", C.c_int32), ("sah_node_cost", C.c_float), ("sah_tri_cost", C.c_float),
-                ("split_alpha", C.c_float), ("n_spatial_bins", C.c_int32)]
+                ("split_alpha", C.c_float), ("n_spatial_bins", C.c_int32), ("optimize_passes", C.c_int32)]
 
 
 class BvhStats(C.Structure):
     _fields_ = [("n_inner", C.c_uint64), ("n_leaves", C.c_uint64), ("n_tri_refs", C.c_uint64),
-                ("max_depth", C.c_uint32), ("sah_cost", C.c_float), ("build_ms", C.c_double)]
+                ("max_depth", C.c_uint32), ("sah_cost", C.c_float), ("build_ms", C.c_double),
+                ("opt_cost_before", C.c_float), ("opt_cost_after", C.c_float)]
 
 
 MAT_DIFF, MAT_METAL, MAT_SPEC, MAT_REFR = 0, 1, 2, 3
@@ -78,7 +79,7 @@ FLAG_NEE = 1 << 8
 FLAGS_SMALLPT = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RUSSIAN_ROULETTE | FLAG_MISS_KEEPS_PATH
 FLAGS_CPU_TRACER = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RR_CPU_TRACER | FLAG_MISS_KEEPS_PATH
 KERNEL_AUTO, KERNEL_MEGA_BVH2, KERNEL_PERSISTENT, KERNEL_WAVEFRONT = 0, 1, 3, 5
-OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT, OPT_WAVE_BLOCKS, OPT_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21
+OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT, OPT_WAVE_BLOCKS, OPT_OVERLAP, OPT_OPTIMIZE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 24
 
 # every symbol include/ptmi.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32

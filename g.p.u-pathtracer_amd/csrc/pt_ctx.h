@@ -57,6 +57,8 @@ struct pt_ctx {
     int n_cu = 0;
     int opt_batch = 36;
     int opt_presplit = 0;        // pt_build_bvh: 0 off, else the target length in per cent of diag/sqrt(n) (PT_OPT_PRESPLIT)
+    int opt_optimize = 0;        // pt_upload_bvh: passes of insertion-based optimisation over the uploaded hierarchy (PT_OPT_OPTIMIZE)
+    double opt_cost[2] = {0.0, 0.0};   // its area cost (inner-node areas / root area) before / after, 0 when it did not run
     int opt_rebuild = 0;         // pt_upload_bvh: 1 = re-cluster the uploaded triangles on the device (PT_OPT_REBUILD)
     int opt_build_algo = 1;      // pt_build_bvh: 0 LBVH (Karras), 1 PLOC (PT_OPT_BUILD_ALGO)
     int opt_sph_lds = 1;         // persistent kernel: sphere attributes from an LDS copy (PT_OPT_SPHERE_LDS)

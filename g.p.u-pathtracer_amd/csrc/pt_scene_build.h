@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "pt_items.h"
+#include "pt_tree_opt.h"
 
 namespace ptscene {
 
@@ -132,8 +133,15 @@ inline Box3 ref_box(const Ref& r) {
     return b;
 }
 
-// splits refs[first, first+count) (count > leaf_max) and returns the child link of the subtree
-inline int32_t split_leaf(Tree& T, uint32_t first, uint32_t count, uint32_t leaf_max, int depth_left) {
+// intersection (a spatial-split builder hands over leaves whose box is the CLIPPED part of their triangles: what is cut out of
+// such a leaf must stay inside it, or boxes grow again when something re-fits them — PT_OPT_OPTIMIZE does)
+inline Box3 clipped(Box3 b, const Box3& bound) {
+    for (int a = 0; a < 3; a++) { b.lo[a] = std::max(b.lo[a], bound.lo[a]); b.hi[a] = std::min(b.hi[a], bound.hi[a]); }
+    return b;
+}
+
+// splits refs[first, first+count) (count > leaf_max) of a leaf with box `bound` and returns the child link of the subtree
+inline int32_t split_leaf(Tree& T, uint32_t first, uint32_t count, uint32_t leaf_max, int depth_left, const Box3& bound) {
     if (count <= leaf_max || depth_left <= 0) {
         T.leaves.push_back(Leaf{first, count});
         return ~(int32_t)(T.leaves.size() - 1);
@@ -166,8 +174,10 @@ inline int32_t split_leaf(Tree& T, uint32_t first, uint32_t count, uint32_t leaf
     BNode bn;
     bn.cb[0].reset(); bn.cb[1].reset();
     for (uint32_t i = 0; i < count; i++) bn.cb[i < best_k ? 0 : 1].grow(ref_box(T.refs[first + i]));
-    bn.child[0] = split_leaf(T, first, best_k, leaf_max, depth_left - 1);
-    bn.child[1] = split_leaf(T, first + best_k, count - best_k, leaf_max, depth_left - 1);
+    bn.cb[0] = clipped(bn.cb[0], bound);
+    bn.cb[1] = clipped(bn.cb[1], bound);
+    bn.child[0] = split_leaf(T, first, best_k, leaf_max, depth_left - 1, bn.cb[0]);
+    bn.child[1] = split_leaf(T, first + best_k, count - best_k, leaf_max, depth_left - 1, bn.cb[1]);
     T.nodes[me] = bn;
     return me;
 }
@@ -182,9 +192,76 @@ inline void refine(Tree& T, uint32_t leaf_max) {
             if (c >= 0) { if ((size_t)c < depth.size()) depth[c] = depth[u] + 1; continue; }
             const Leaf lf = T.leaves[~c];
             if (lf.count <= leaf_max) continue;
-            const int32_t link = split_leaf(T, lf.first, lf.count, leaf_max, 64 - (int)depth[u] - 1);
+            const Box3 bound = T.nodes[u].cb[i];   // a copy: split_leaf appends to T.nodes
+            const int32_t link = split_leaf(T, lf.first, lf.count, leaf_max, 64 - (int)depth[u] - 1, bound);
             T.nodes[u].child[i] = link;  // the old leaf entry is orphaned (never referenced again)
         }
+}
+
+// ---- 2b. optimise (PT_OPT_OPTIMIZE): insertion-based optimisation of the hierarchy as it stands after `refine` ---------------
+// pt_tree_opt.h works on index arrays: inner nodes keep their numbers, leaf k becomes node n_inner + k.  Returns the tree's area
+// cost (sum of inner-node areas / root area) before and after; a result deeper than `max_depth` is thrown away.
+inline bool optimize(Tree& T, int passes, uint32_t max_depth, double& cost_before, double& cost_after) {
+    cost_before = cost_after = 0.0;
+    const size_t n_in = T.nodes.size();
+    if (passes <= 0 || n_in < 2) return false;
+    // only what is reachable from the root (refine orphans the leaves it splits; their entries stay in T.leaves)
+    pttreeopt::Tree O;
+    std::vector<int32_t> leaf_of;        // O index -> leaf index (or -1)
+    auto box6 = [](const Box3& b) { pttreeopt::Box6 r; for (int a = 0; a < 3; a++) { r.lo[a] = b.lo[a]; r.hi[a] = b.hi[a]; } return r; };
+    {
+        Box3 rb = T.nodes[0].cb[0];
+        rb.grow(T.nodes[0].cb[1]);
+        O.root = O.add(box6(rb), -1);
+        leaf_of.push_back(-1);
+        std::vector<std::pair<size_t, int>> st{{0, O.root}};
+        while (!st.empty()) {
+            const std::pair<size_t, int> it = st.back();
+            st.pop_back();
+            int kid[2];
+            for (int i = 0; i < 2; i++) {
+                const int32_t c = T.nodes[it.first].child[i];
+                kid[i] = O.add(box6(T.nodes[it.first].cb[i]), it.second);
+                leaf_of.push_back(c < 0 ? ~c : -1);
+                if (c >= 0) st.push_back({(size_t)c, kid[i]});
+            }
+            O.c0[it.second] = kid[0]; O.c1[it.second] = kid[1];
+        }
+    }
+    cost_before = cost_after = O.cost();
+    for (int p = 0; p < passes; p++) {
+        const size_t moved = pttreeopt::reinsertion_pass(O);
+        if (moved == 0) break;
+    }
+    if (O.depth() > max_depth) return false;
+    cost_after = O.cost();
+    // back to BNodes: the root must be nodes[0]; inner nodes are renumbered in the order they are met
+    std::vector<BNode> out;
+    out.reserve(n_in);
+    std::vector<int32_t> new_idx(O.box.size(), -1);
+    std::vector<int> order{O.root};
+    new_idx[O.root] = 0;
+    out.push_back(BNode());
+    for (size_t k = 0; k < order.size(); k++) {
+        const int u = order[k];
+        BNode bn;
+        const int kid[2] = {O.c0[u], O.c1[u]};
+        for (int i = 0; i < 2; i++) {
+            const pttreeopt::Box6& b = O.box[kid[i]];
+            for (int a = 0; a < 3; a++) { bn.cb[i].lo[a] = b.lo[a]; bn.cb[i].hi[a] = b.hi[a]; }
+            if (O.leaf(kid[i])) {
+                bn.child[i] = ~leaf_of[kid[i]];
+            } else {
+                new_idx[kid[i]] = (int32_t)out.size();
+                bn.child[i] = new_idx[kid[i]];
+                out.push_back(BNode());
+                order.push_back(kid[i]);
+            }
+        }
+        out[(size_t)new_idx[u]] = bn;
+    }
+    T.nodes.swap(out);
+    return true;
 }
 
 // ---- 3. emit ----------------------------------------------------------------------------

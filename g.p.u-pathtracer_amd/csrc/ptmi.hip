@@ -221,6 +221,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             (option == PT_OPT_VOTE_NODE ? c->opt_vote_node : c->opt_vote_rec) = value;
             return PT_OK;
         case PT_OPT_OVERLAP: c->opt_overlap = value != 0; return PT_OK;
+        case PT_OPT_OPTIMIZE:
+            if (value < 0 || value > 16) return fail(c, PT_ERR_INVALID, "pt_set_option: optimize passes must be 0 (off) .. 16");
+            c->opt_optimize = value;   // takes effect at the next pt_upload_bvh
+            return PT_OK;
         case PT_OPT_WAVE_BLOCKS:
             if (value < 1 || value > 8) return fail(c, PT_ERR_INVALID, "pt_set_option: wave blocks must be 1..8 per CU");
             c->opt_wave_blocks = value;
@@ -337,6 +341,11 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
     };
     if (rebuild == 1) return recluster();
     ptscene::refine(T, (uint32_t)c->opt_leaf_max);
+    c->opt_cost[0] = c->opt_cost[1] = 0.0;
+    if (c->opt_optimize > 0) {   // PT_OPT_OPTIMIZE: every node of the caller's hierarchy re-inserted where the area cost grows least
+        double before = 0.0, after = 0.0;
+        if (ptscene::optimize(T, c->opt_optimize, 64, before, after)) { c->opt_cost[0] = before; c->opt_cost[1] = after; }
+    }
     ptscene::Output O;
     ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
     const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);

@@ -2,6 +2,7 @@
 // reference files this stands in for).  Clean-room: written from the layout/behaviour
 // description in SURVEY.md §2/§8(a12), not from the reference's builder sources.
 #include "pthost.h"
+#include "../csrc/pt_tree_opt.h"
 
 #include <algorithm>
 #include <chrono>
@@ -355,6 +356,60 @@ struct Builder {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pth_build_params::optimize_passes (extension): insertion-based optimisation of the finished hierarchy, ../csrc/pt_tree_opt.h.
+// Node tree -> index arrays -> passes -> Node tree; a leaf keeps its triangle list and its (possibly clipped) box.
+struct OptBridge {
+    pttreeopt::Tree T;
+    std::vector<const Node*> src;   // node index -> the builder's node (leaf payload)
+
+    static pttreeopt::Box6 box6(const Box& b) { return {{b.lo.x, b.lo.y, b.lo.z}, {b.hi.x, b.hi.y, b.hi.z}}; }
+    void from(const Node* r) {
+        struct It { const Node* n; int idx; };
+        T.root = T.add(box6(r->box), -1);
+        src.push_back(r);
+        std::vector<It> st{{r, T.root}};
+        while (!st.empty()) {
+            const It it = st.back();
+            st.pop_back();
+            if (it.n->leaf()) continue;
+            const int a = T.add(box6(it.n->child[0]->box), it.idx);
+            src.push_back(it.n->child[0].get());
+            const int b = T.add(box6(it.n->child[1]->box), it.idx);
+            src.push_back(it.n->child[1].get());
+            T.c0[it.idx] = a; T.c1[it.idx] = b;
+            st.push_back({it.n->child[0].get(), a});
+            st.push_back({it.n->child[1].get(), b});
+        }
+    }
+    std::unique_ptr<Node> to_nodes() const {   // children before parents: post-order through an explicit stack
+        std::vector<std::unique_ptr<Node>> made(T.box.size());
+        std::vector<std::pair<int, bool>> st{{T.root, false}};
+        auto boxof = [&](int i) { Box b; b.lo = {T.box[i].lo[0], T.box[i].lo[1], T.box[i].lo[2]}; b.hi = {T.box[i].hi[0], T.box[i].hi[1], T.box[i].hi[2]}; return b; };
+        while (!st.empty()) {
+            const std::pair<int, bool> it = st.back();
+            st.pop_back();
+            const int i = it.first;
+            if (T.leaf(i)) {
+                made[i] = std::make_unique<Node>();
+                made[i]->box = src[i]->box;
+                made[i]->tris = src[i]->tris;
+            } else if (!it.second) {
+                st.push_back({i, true});
+                st.push_back({T.c0[i], false});
+                st.push_back({T.c1[i], false});
+            } else {
+                made[i] = std::make_unique<Node>();
+                made[i]->box = boxof(i);
+                made[i]->child[0] = std::move(made[T.c0[i]]);
+                made[i]->child[1] = std::move(made[T.c1[i]]);
+            }
+        }
+        return std::move(made[T.root]);
+    }
+};
+
 struct FlattenCtx {
     std::vector<float>& nodes;
     std::vector<float>& tris;
@@ -449,6 +504,7 @@ void pth_default_build_params(pth_build_params* p) {
     p->sah_tri_cost = 1.f;
     p->split_alpha = 1e-5f;  // BuildParams::splitAlpha of the reference (SBVH)
     p->n_spatial_bins = 32;
+    p->optimize_passes = 0;
 }
 
 pth_mesh* pth_mesh_create(const float* verts, size_t n_verts, const int32_t* tris, size_t n_tris) {
@@ -694,6 +750,20 @@ pth_bvh* pth_bvh_build(const pth_mesh* mesh, const pth_build_params* params) {
 #pragma omp single
     tree = b.build(refs, root, 0, true);
 
+    double opt_before = 0.0, opt_after = 0.0;
+    if (P.optimize_passes > 0 && !tree->leaf()) {
+        OptBridge ob;
+        ob.from(tree.get());
+        opt_before = opt_after = ob.T.cost();
+        for (int pass = 0; pass < P.optimize_passes; pass++) {
+            const size_t moved = pttreeopt::reinsertion_pass(ob.T);
+            opt_after = ob.T.cost();
+            if (moved == 0) break;
+        }
+        if (ob.T.depth() <= (uint32_t)P.max_depth) tree = ob.to_nodes();   // else: keep the builder's tree (the Compact layout caps the depth)
+        else opt_after = opt_before;
+    }
+
     if (tree->leaf()) {  // wrap a root leaf (CudaBVH.cpp:141 asserts)
         auto top = std::make_unique<Node>();
         top->box = tree->box;
@@ -713,6 +783,8 @@ pth_bvh* pth_bvh_build(const pth_mesh* mesh, const pth_build_params* params) {
     out->stats.max_depth = fc.max_depth;
     out->stats.sah_cost = (float)fc.sah;
     out->stats.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out->stats.opt_cost_before = (float)opt_before;
+    out->stats.opt_cost_after = (float)opt_after;
     return out;
 }
 

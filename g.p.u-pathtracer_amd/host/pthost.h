@@ -44,6 +44,9 @@ typedef struct pth_build_params {
     float sah_tri_cost;      /* Platform::m_SAHTriangleCost = 1                            */
     float split_alpha;       /* BuildParams::splitAlpha = 1e-5; < 0 disables spatial splits */
     int32_t n_spatial_bins;  /* SplitBVHBuilder NumSpatialBins = 32                         */
+    int32_t optimize_passes; /* EXTENSION (0 = off, the reference's tree as built): passes of insertion-based optimisation
+                                over the finished hierarchy (Bittner et al. 2013): every node is re-inserted where the tree's
+                                surface-area cost grows least; closest hits unchanged                                    */
 } pth_build_params;
 
 typedef struct pth_bvh_stats {
@@ -51,6 +54,7 @@ typedef struct pth_bvh_stats {
     uint32_t max_depth;      /* edges on the longest root-to-leaf path                      */
     float sah_cost;
     double build_ms;
+    float opt_cost_before, opt_cost_after;   /* sum of inner-node areas / root area, before / after optimize_passes (0 if off) */
 } pth_bvh_stats;
 
 const char* pth_last_error(void);

@@ -300,3 +300,43 @@ def test_rebuild_2_keeps_the_cheaper_tree():
             t.set_option(g.OPT_REBUILD, 3)
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("scene", ["gto_sixteen", "cornell_dragon"])
+def test_upload_time_optimisation_keeps_hits_and_lowers_the_cost(scene):
+    """PT_OPT_OPTIMIZE: the uploaded hierarchy re-arranged by insertion-based optimisation (csrc/pt_tree_opt.h) before it is
+    emitted.  Ray batches == brute force bit for bit (t, id, normal), the frame == the oracle's over the caller's own tree,
+    and the 4-wide tree's area cost in node visits drops."""
+    mesh = g.scene_mesh(scene)
+    bvh = g.Bvh(mesh)
+    lo, hi = mesh.bounds()
+    rays = np.concatenate([orc.random_rays(60000, lo, hi, seed=3), orc.primary_rays(g.default_camera(320, 180), 320, 180, frame=1)[::7]])
+    W, H = 480, 270
+    cam, p = g.default_camera(W, H), g.default_params(W, H)
+    p.frame = 2
+    sph = g.reference_spheres()
+    ref, _, _ = orc.render(bvh, sph, cam, p, 2, want_rgba=False)
+    tb, ib, nb = orc.trace_brute(mesh, rays)
+    t = g.PathTracer(0)
+    try:
+        costs = {}
+        for passes in (0, 2):
+            t.set_option(g.OPT_OPTIMIZE, passes)
+            t.upload_bvh(bvh)
+            costs[passes] = t.tree_cost()[0]
+            tg, ig, ng = gpu_trace(t, rays)
+            assert np.array_equal(tg, tb) and np.array_equal(ig, ib)
+            hit = ib >= 0
+            assert np.array_equal(ng[hit], nb[hit])
+            t.upload_spheres(sph)
+            acc, rgba = t.alloc_frame(W, H)
+            t.launch_kernel(acc.ptr, rgba.ptr, cam, p, 2)
+            t.sync()
+            got = acc.download(np.float32, (H, W, 3))
+            acc.free()
+            rgba.free()
+            assert int(np.any(got != ref, axis=-1).sum()) <= 2
+        print(f"{scene}: area cost in node visits {costs[0]:.3f} -> {costs[2]:.3f}")
+        assert costs[2] < costs[0]
+    finally:
+        t.close()

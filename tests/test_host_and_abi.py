@@ -247,3 +247,29 @@ def test_bench_pmc_csv_parsing(tmp_path):
     assert bench.pmc_values(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE", "k_wf_extend") == [1000.0, 3000.0]
     assert bench.pmc_values(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE", "k_fold_samples") == [7.0]
     assert bench.pmc_values(str(tmp_path / "FETCH_SIZE"), "WRITE_SIZE", "k_wf_shade") == []
+
+
+@pytest.mark.parametrize("scene", ["gto_sixteen", "cornell_dragon", "bunny_low"])
+def test_insertion_optimised_tree_keeps_every_hit_and_costs_less(scene):
+    """pth_build_params.optimize_passes (extension): every node re-inserted where the tree's area cost grows least.  The
+    flattened tree holds the same triangle references, stays within the Compact layout's depth, costs less, and the oracle's
+    walk over it reports the closest hits of the plain tree and of brute force bit for bit (gto_sixteen: spatial-split
+    references with clipped boxes move around too)."""
+    import orc
+    mesh = g.scene_mesh(scene)
+    plain, opt = g.Bvh(mesh), g.Bvh(mesh, optimize_passes=2)
+    assert opt.stats["n_tri_refs"] == plain.stats["n_tri_refs"] and opt.stats["n_leaves"] == plain.stats["n_leaves"]
+    assert opt.stats["max_depth"] <= 64
+    assert 0 < opt.stats["opt_cost_after"] < 0.99 * opt.stats["opt_cost_before"]
+    assert opt.stats["sah_cost"] < plain.stats["sah_cost"]
+    assert sorted(opt.index[::1][opt.tris.view(np.uint32)[:, 0] != 0x80000000][::3].tolist()) == \
+        sorted(plain.index[::1][plain.tris.view(np.uint32)[:, 0] != 0x80000000][::3].tolist())
+    lo, hi = mesh.bounds()
+    rays = orc.random_rays(20000, lo, hi, seed=11)
+    for cull in (True, False):
+        t0, i0, n0, _ = orc.trace_bvh(plain, rays, cull)
+        t1, i1, n1, c1 = orc.trace_bvh(opt, rays, cull)
+        tb, ib, nb = orc.trace_brute(mesh, rays, cull)
+        assert np.array_equal(t1, tb) and np.array_equal(i1, ib)
+        assert np.array_equal(t0, t1) and np.array_equal(i0, i1)
+        assert (ib >= 0).mean() > 0.05

@@ -13,6 +13,9 @@ args = sys.argv[1:]
 scene, spp, dev_build, node_width, occ, no_splits = "cornell_dragon_800k", 16, False, None, None, False
 cfgs = []
 keep = False
+bvh_kw = {}
+rebuild = None
+optimize = 0
 while args:
     a = args.pop(0)
     if a == "--scene": scene = args.pop(0)
@@ -22,6 +25,13 @@ while args:
     elif a == "--occ": occ = int(args.pop(0))
     elif a == "--no-splits": no_splits = True
     elif a == "--keep": keep = True
+    elif a == "--bvh":   # host builder parameters: k=v,k=v (pth_build_params fields); implies --keep unless --rebuild N is given
+        keep = True
+        for kv in args.pop(0).split(","):
+            k, v = kv.split("=")
+            bvh_kw[k] = float(v) if k in ("split_alpha", "sah_node_cost", "sah_tri_cost") else int(v)
+    elif a == "--rebuild": rebuild = int(args.pop(0))
+    elif a == "--optimize": optimize = int(args.pop(0))   # PT_OPT_OPTIMIZE passes at upload
     else: cfgs.append(tuple(int(x) for x in a.split(":")))
 W, H = 1920, 1080
 pt = g.PathTracer(0)
@@ -35,13 +45,18 @@ t0 = time.perf_counter()
 if dev_build:
     pt.build_bvh(mesh)
 else:
-    bvh = g.Bvh(mesh, split_alpha=-1.0) if no_splits else g.Bvh(mesh)
+    bvh = g.Bvh(mesh, split_alpha=-1.0) if no_splits else g.Bvh(mesh, **bvh_kw)
     t1 = time.perf_counter()
-    if not no_splits and not keep:
+    if bvh_kw:
+        print("host tree", bvh_kw, {k: bvh.stats[k] for k in ("n_inner", "n_tri_refs", "max_depth", "sah_cost", "opt_cost_before", "opt_cost_after")}, flush=True)
+    pt.set_option(g.OPT_OPTIMIZE, optimize)
+    if rebuild is not None:
+        pt.set_option(g.OPT_REBUILD, rebuild)
+    elif not no_splits and not keep:
         pt.set_option(g.OPT_REBUILD, 2)
     pt.upload_bvh(bvh); pt.set_option(g.OPT_REBUILD, 0)
     print(f"host build {t1 - t0:.1f} s, upload {time.perf_counter() - t1:.1f} s", flush=True)
-print("scene", pt.scene_info(), flush=True)
+print("scene", pt.scene_info(), "area cost (node visits, tri tests)", tuple(round(x, 3) for x in pt.tree_cost()), flush=True)
 pt.upload_spheres(g.reference_spheres())
 cam = g.default_camera(W, H); acc, rgba = pt.alloc_frame(W, H)
 def run(n, first=0):
