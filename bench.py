@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--no-cpu-reference", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (materials, 1 spp, device tree, big scene, gather bound)")
     ap.add_argument("--device-build", action="store_true", help="build the BVH on the device (pt_build_bvh) instead of the host SBVH builder")
+    ap.add_argument("--host-splits", action="store_true", help="host tree with the builder's spatial splits (the reference's splitAlpha = 1e-5)")
     ap.add_argument("--keep-hierarchy", action="store_true",
                     help="PT_OPT_REBUILD 0: walk the uploaded hierarchy whatever it costs (default: PT_OPT_REBUILD 2, the upload also "
                          "re-clusters the triangles on the device and keeps the tree with the smaller area cost in node visits)")
@@ -264,7 +265,9 @@ def main():
     W, H = a.width, a.height
     mat = {"diff": g.MAT_DIFF, "metal": g.MAT_METAL, "spec": g.MAT_SPEC, "refr": g.MAT_REFR}[a.mat]
     mesh = g.scene_mesh(a.scene)
-    bvh = None if a.device_build else g.Bvh(mesh)
+    # the host tree: the clean-room SBVH builder (host/pthost.cpp) WITHOUT its spatial splits — once the upload optimises the hierarchy
+    # (PT_OPT_OPTIMIZE) they no longer pay on this scene (9.00 vs 8.87 ms per step: profiles/r03_tree_opt.txt); --host-splits keeps them
+    bvh = None if a.device_build else (g.Bvh(mesh) if a.host_splits else g.Bvh(mesh, split_alpha=-1.0))
     sph = None if a.no_spheres else g.reference_spheres()
     n_sph = 0 if sph is None else len(sph)
     cam = g.default_camera(W, H)
@@ -306,9 +309,10 @@ def main():
         t_up = time.perf_counter() - t_up
         pt.set_option(g.OPT_REBUILD, 0)
         pt.set_option(g.OPT_OPTIMIZE, 0)
-        tree_note = ("host SBVH hierarchy, uploaded as built (PT_OPT_OPTIMIZE 0, PT_OPT_REBUILD 0)" if a.keep_hierarchy else
-                     f"host SBVH hierarchy uploaded with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2 ({t_up:.1f} s): kept " +
-                     ("the device's re-clustered tree" if pt.last_build_ms() > 0 else "the uploaded hierarchy, optimised"))
+        host_kind = "host SBVH hierarchy" if a.host_splits else "host SAH hierarchy (no spatial splits)"
+        tree_note = (f"{host_kind}, uploaded as built (PT_OPT_OPTIMIZE 0, PT_OPT_REBUILD 0)" if a.keep_hierarchy else
+                     f"{host_kind} uploaded with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2 ({t_up:.1f} s): kept " +
+                     ("the device's re-clustered tree, optimised" if pt.last_build_ms() > 0 else "the uploaded hierarchy, optimised"))
     pt.upload_spheres(sph)
     info = pt.scene_info()
     try:
@@ -558,7 +562,7 @@ def main():
             # ACHIEVED = traffic / the kernel's HIP-event duration; FRAC = achieved / 8 TB/s — the fraction of the HBM roofline
             # the kernel really draws (north_star's figure).  Infinity-Cache hits are inside FETCH_SIZE (MI355X_MICROARCH.md),
             # so on a scene that fits the 256 MB cache this is an UPPER bound of what reaches HBM.
-            scene_args = ["--scene", a.scene, "--width", str(W), "--height", str(H), "--spp", str(a.spp), "--depth", str(a.depth), "--mat", a.mat,
+            scene_args = (["--host-splits"] if a.host_splits else []) + ["--scene", a.scene, "--width", str(W), "--height", str(H), "--spp", str(a.spp), "--depth", str(a.depth), "--mat", a.mat,
                           "--kernel", str(timed_kernel)] + (["--no-spheres"] if a.no_spheres else []) + (["--device-build"] if a.device_build else []) + \
                          (["--keep-hierarchy"] if a.keep_hierarchy else [])
             tr = None

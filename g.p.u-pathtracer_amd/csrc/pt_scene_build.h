@@ -126,6 +126,59 @@ inline bool parse(const float* nodes, size_t n_node_vec4, const float* tri_verts
     return true;
 }
 
+// ---- 1b. a Tree from the item buffer's own binary nodes + records (what the device builder leaves on the context) --------
+// bin: 16 floats per node ([c0.lo.x c0.hi.x c0.lo.y c0.hi.y][c1 ...][c0.lo.z c0.hi.z c1.lo.z c1.hi.z][link0 link1 0 0], links as
+// float4 indices into the item buffer, < 0: ~(first record of a leaf)), node 0 = root; rec: 16 floats per record (id in [3],
+// `last` flag in [7]).  The vertices come from `by_id` (the caller's own, bit for bit), not from the records' edges.
+inline bool from_items(const float* bin, size_t n_bin, const float* rec, size_t n_rec, const std::vector<const float*>& by_id, Tree& T,
+                       std::string& err) {
+    T.nodes.clear(); T.leaves.clear(); T.refs.clear();
+    if (n_bin == 0) { err = "no nodes"; return false; }
+    const size_t rec_base = 4 * n_bin;
+    std::vector<int32_t> map(n_bin, -1);
+    std::vector<size_t> order{0};
+    map[0] = 0;
+    T.nodes.push_back(BNode());
+    for (size_t k = 0; k < order.size(); k++) {
+        const float* s = bin + 16 * order[k];
+        BNode bn;
+        for (int i = 0; i < 2; i++) {
+            bn.cb[i].lo[0] = s[0 + 4 * i]; bn.cb[i].hi[0] = s[1 + 4 * i];
+            bn.cb[i].lo[1] = s[2 + 4 * i]; bn.cb[i].hi[1] = s[3 + 4 * i];
+            bn.cb[i].lo[2] = s[8 + 2 * i]; bn.cb[i].hi[2] = s[9 + 2 * i];
+            const int32_t l = f2i(s[12 + i]);
+            if (l >= 0) {
+                const size_t cidx = (size_t)l / 4;
+                if ((l % 4) != 0 || cidx >= n_bin || map[cidx] != -1) { err = "bad inner link"; return false; }
+                map[cidx] = (int32_t)T.nodes.size();
+                bn.child[i] = map[cidx];
+                T.nodes.push_back(BNode());
+                order.push_back(cidx);
+            } else {
+                const size_t r = (size_t)(~l);
+                if (r < rec_base || ((r - rec_base) % 4) != 0) { err = "bad leaf link"; return false; }
+                Leaf lf;
+                lf.first = (uint32_t)T.refs.size();
+                for (size_t ri = (r - rec_base) / 4;; ri++) {
+                    if (ri >= n_rec) { err = "leaf runs past the records"; return false; }
+                    const int32_t id = f2i(rec[16 * ri + 3]);
+                    if (id < 0 || (size_t)id >= by_id.size() || !by_id[(size_t)id]) { err = "record of an unknown triangle"; return false; }
+                    Ref rf;
+                    std::memcpy(rf.v, by_id[(size_t)id], 9 * sizeof(float));
+                    rf.id = id;
+                    T.refs.push_back(rf);
+                    if (f2i(rec[16 * ri + 7]) != 0) break;
+                }
+                lf.count = (uint32_t)T.refs.size() - lf.first;
+                bn.child[i] = ~(int32_t)T.leaves.size();
+                T.leaves.push_back(lf);
+            }
+        }
+        T.nodes[k] = bn;
+    }
+    return true;
+}
+
 // ---- 2. refine big leaves --------------------------------------------------------------
 inline Box3 ref_box(const Ref& r) {
     Box3 b; b.reset();

@@ -339,60 +339,87 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
             rc = build_bvh_impl(c, verts.data(), verts.size() / 3, tri_rows.data(), ids.size(), 0, &too_deep, ids.data());
         return rc;
     };
-    if (rebuild == 1) return recluster();
-    ptscene::refine(T, (uint32_t)c->opt_leaf_max);
-    c->opt_cost[0] = c->opt_cost[1] = 0.0;
-    if (c->opt_optimize > 0) {   // PT_OPT_OPTIMIZE: every node of the caller's hierarchy re-inserted where the area cost grows least
-        double before = 0.0, after = 0.0;
-        if (ptscene::optimize(T, c->opt_optimize, 64, before, after)) { c->opt_cost[0] = before; c->opt_cost[1] = after; }
+    // refine (leaves of at most PT_OPT_LEAF_MAX references), optimise (PT_OPT_OPTIMIZE), emit, upload: the tree `X` becomes the context's
+    auto install = [&](ptscene::Tree& X) -> int {
+        ptscene::refine(X, (uint32_t)c->opt_leaf_max);
+        c->opt_cost[0] = c->opt_cost[1] = 0.0;
+        if (c->opt_optimize > 0 && c->opt_tri_test == 0) {   // every node re-inserted where the area cost grows least (pt_tree_opt.h)
+            double before = 0.0, after = 0.0;
+            if (ptscene::optimize(X, c->opt_optimize, 64, before, after)) { c->opt_cost[0] = before; c->opt_cost[1] = after; }
+        }
+        ptscene::Output O;
+        ptscene::emit(X, PT_MAX_TOP, O, c->opt_tri_test == 1);
+        const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
+        if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
+        c->d_tris = nullptr;
+        c->has_bvh = false;
+        HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb + wb));
+        c->d_tris = c->d_nodes;  // one item buffer: links index it directly
+        HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
+        c->records_woop = c->opt_tri_test == 1;
+        c->wide_root = O.wide_root_f4;
+        c->wide_top_layout = O.n_top_wide;
+        c->wide_depth = O.depth_wide;
+        c->n_wide = O.wide.size() / 16;
+        c->n_top_layout = O.n_top_bin;
+        c->n_inner = O.bin.size() / 16;
+        c->n_refs = O.n_refs;
+        c->n_leaves = O.n_leaves;
+        c->max_depth = O.depth_bin;
+        c->scene_bytes = nb + tb + wb;
+        c->max_tri_id = max_id;
+        c->has_bvh = true;
+        c->build_ms = -1.f;   // no device build stands behind this tree (the callers below put it back when one does)
+        c->scene_gen++;
+        return PT_OK;
+    };
+    // PT_OPT_REBUILD with PT_OPT_OPTIMIZE: the re-clustered hierarchy comes back from the device (binary nodes + the records' ids),
+    // is optimised like an uploaded one and installed in its place; the device build's time stays on the context
+    auto optimise_reclustered = [&]() -> int {
+        if (c->opt_optimize <= 0 || !c->has_bvh || c->records_woop) return PT_OK;
+        const size_t n_bin = (size_t)c->n_inner, n_rec = (size_t)c->n_refs;
+        std::vector<float> bin(16 * n_bin), rec(16 * n_rec);
+        HIP_TRY(c, hipMemcpy(bin.data(), c->d_nodes, bin.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(rec.data(), (const char*)c->d_nodes + bin.size() * sizeof(float), rec.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<const float*> by_id((size_t)max_id + 1, nullptr);
+        for (const ptscene::Ref& r : T.refs) if (!by_id[(size_t)r.id]) by_id[(size_t)r.id] = r.v;
+        ptscene::Tree X;
+        std::string why;
+        if (!ptscene::from_items(bin.data(), n_bin, rec.data(), n_rec, by_id, X, why)) return fail(c, PT_ERR_DEVICE, "pt_upload_bvh: re-clustered tree: " + why);
+        const float device_ms = c->build_ms;
+        const int rc = install(X);
+        if (rc == PT_OK) c->build_ms = device_ms;
+        return rc;
+    };
+    if (rebuild == 1) {
+        const int rc = recluster();
+        return rc == PT_OK ? optimise_reclustered() : rc;
     }
-    ptscene::Output O;
-    ptscene::emit(T, PT_MAX_TOP, O, c->opt_tri_test == 1);
-    const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
-    if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
-
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
-    c->d_tris = nullptr;
-    c->has_bvh = false;
-    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb + wb));
-    c->d_tris = c->d_nodes;  // one item buffer: links index it directly
-    HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
-    c->records_woop = c->opt_tri_test == 1;
-    c->wide_root = O.wide_root_f4;
-    c->wide_top_layout = O.n_top_wide;
-    c->wide_depth = O.depth_wide;
-    c->n_wide = O.wide.size() / 16;
-    c->n_top_layout = O.n_top_bin;
-    const size_t n_out = O.bin.size() / 16;
-    const uint64_t n_refs = O.n_refs, n_leaves = O.n_leaves;
-    const uint32_t max_depth = O.depth_bin;
-    c->n_inner = n_out;
-    c->n_refs = n_refs;
-    c->n_leaves = n_leaves;
-    c->max_depth = max_depth;
-    c->scene_bytes = nb + tb + wb;
-    c->max_tri_id = max_id;
-    c->has_bvh = true;
-    c->build_ms = -1.f;   // an uploaded hierarchy: no device build stands behind this tree
-    c->scene_gen++;
+    {
+        const int rc = install(T);
+        if (rc != PT_OK) return rc;
+    }
     if (rebuild == 2 && c->n_wide > 0) {
         // PT_OPT_REBUILD 2: the caller's hierarchy is up; build the re-clustered one beside it and keep whichever costs a
         // random ray fewer wide-node visits (pt_tree_cost).  A failure on the way leaves the caller's tree in place.
         double cost_a = 0.0, cost_b = 0.0, unused = 0.0;
         if (tree_cost_impl(c, &cost_a, &unused) != PT_OK) return PT_OK;
         const TreeState mine = TreeState::of(c);
+        const double mine_opt[2] = {c->opt_cost[0], c->opt_cost[1]};
         c->d_nodes = nullptr;   // the builder frees the context's buffer before it installs its own
         c->d_tris = nullptr;
-        const bool built = recluster() == PT_OK && c->d_nodes != nullptr;
+        const bool built = recluster() == PT_OK && c->d_nodes != nullptr && optimise_reclustered() == PT_OK && c->d_nodes != nullptr;
         if (built && tree_cost_impl(c, &cost_b, &unused) == PT_OK && cost_b < cost_a) {
             (void)hipFree(mine.d_nodes);
         } else {
             if (c->d_nodes != mine.d_nodes) (void)hipFree(c->d_nodes);
             mine.restore(c);
+            c->opt_cost[0] = mine_opt[0]; c->opt_cost[1] = mine_opt[1];
             c->err.clear();
         }
         c->scene_gen++;

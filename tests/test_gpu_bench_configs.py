@@ -19,9 +19,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=["default", "cheaper-tree", "wavefront", "persistent"])
 def ptd(request):
-    """default = whatever PT_KERNEL_AUTO picks; cheaper-tree = the same with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2, which is what
-    bench.py times (the upload optimises the caller's hierarchy by re-insertion, re-clusters the triangles on the device as well
-    and keeps whichever hierarchy costs fewer node visits); the two stage layouts named too."""
+    """default = whatever PT_KERNEL_AUTO picks; cheaper-tree = the same with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2 over a host tree
+    built without spatial splits, which is what bench.py times (the upload optimises the caller's hierarchy by re-insertion,
+    re-clusters the triangles on the device and optimises that too, and keeps whichever hierarchy costs fewer node visits);
+    the two stage layouts named too."""
     t = g.PathTracer(0)
     if request.param == "wavefront":
         t.set_option(g.OPT_KERNEL, g.KERNEL_WAVEFRONT)
@@ -31,6 +32,9 @@ def ptd(request):
         t.set_option(g.OPT_OPTIMIZE, 2)
         t.set_option(g.OPT_REBUILD, 2)
     t.variant = request.param
+    # bench.py's host tree is built without spatial splits (with PT_OPT_OPTIMIZE they no longer pay on its scene): the variant that
+    # mirrors bench.py uploads THAT tree; the oracle walks the default host tree (closest hits do not depend on the tree)
+    t.upload_tree = (lambda name: bvh_of(name, split_alpha=-1.0)[1]) if request.param == "cheaper-tree" else (lambda name: bvh_of(name)[1])
     yield t
     t.close()
 
@@ -66,7 +70,7 @@ def test_bench_step_16spp_800k_full_frame(ptd):
     rng = np.random.default_rng(5)
     prev = rng.random((H, W, 3), dtype=np.float32)
     ref, ref_rgba, cnt = oracle("step16", lambda: orc.render(bvh, sph, cam, p, spp, accum=prev.copy()))
-    acc, rgba = gpu_render(ptd, bvh, sph, cam, p, spp, accum_init=prev)
+    acc, rgba = gpu_render(ptd, ptd.upload_tree("cornell_dragon_800k"), sph, cam, p, spp, accum_init=prev)
     assert cnt["rays"] == W * H * spp * p.depth          # the closed room: every path runs all four segments
     check(acc, ref, f"[{ptd.variant}] 800k diffuse 16 spp/call", 40)
     assert int((rgba != ref_rgba).sum()) <= 40
@@ -82,7 +86,7 @@ def test_800k_metal_and_specular_full_frame(ptd, mat):
     p = g.default_params(W, H, tri_mat=mat)
     p.frame = 3
     ref, _, _ = oracle(("mat", mat), lambda: orc.render(bvh, sph, cam, p, spp, want_rgba=False))
-    acc, _ = gpu_render(ptd, bvh, sph, cam, p, spp)
+    acc, _ = gpu_render(ptd, ptd.upload_tree("cornell_dragon_800k"), sph, cam, p, spp)
     check(acc, ref, f"[{ptd.variant}] 800k mat {mat} {spp} spp", 40)
 
 
@@ -216,7 +220,7 @@ def test_bench_step_differing_pixels_are_brute_force_hits(ptd):
     sph = g.reference_spheres()
     cam = g.default_camera(W, H)
     p = g.default_params(W, H)
-    ptd.upload_bvh(bvh)
+    ptd.upload_bvh(ptd.upload_tree("cornell_dragon_800k"))
     ptd.upload_spheres(sph)
     # frames 80..95: the first timed step of `bench.py --steps 20 --warmup 5` (what the round-end driver runs), where round 2's
     # in-run parity counted 2 differing pixels of 2 073 600

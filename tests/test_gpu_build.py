@@ -304,9 +304,10 @@ def test_rebuild_2_keeps_the_cheaper_tree():
 
 @pytest.mark.parametrize("scene", ["gto_sixteen", "cornell_dragon"])
 def test_upload_time_optimisation_keeps_hits_and_lowers_the_cost(scene):
-    """PT_OPT_OPTIMIZE: the uploaded hierarchy re-arranged by insertion-based optimisation (csrc/pt_tree_opt.h) before it is
-    emitted.  Ray batches == brute force bit for bit (t, id, normal), the frame == the oracle's over the caller's own tree,
-    and the 4-wide tree's area cost in node visits drops."""
+    """PT_OPT_OPTIMIZE: the uploaded hierarchy — and, with PT_OPT_REBUILD, the device's re-clustered one, fetched back — re-arranged
+    by insertion-based optimisation (csrc/pt_tree_opt.h) before it is emitted.  Ray batches == brute force bit for bit (t, id,
+    normal), the frame == the oracle's over the caller's own tree, the 4-wide tree's area cost in node visits drops, and
+    PT_OPT_REBUILD 2 keeps the cheaper of the two optimised trees."""
     mesh = g.scene_mesh(scene)
     bvh = g.Bvh(mesh)
     lo, hi = mesh.bounds()
@@ -320,10 +321,13 @@ def test_upload_time_optimisation_keeps_hits_and_lowers_the_cost(scene):
     t = g.PathTracer(0)
     try:
         costs = {}
-        for passes in (0, 2):
+        for rebuild, passes in ((0, 0), (0, 2), (1, 0), (1, 2), (2, 2)):
             t.set_option(g.OPT_OPTIMIZE, passes)
+            t.set_option(g.OPT_REBUILD, rebuild)
             t.upload_bvh(bvh)
-            costs[passes] = t.tree_cost()[0]
+            t.set_option(g.OPT_REBUILD, 0)
+            t.set_option(g.OPT_OPTIMIZE, 0)
+            costs[(rebuild, passes)] = t.tree_cost()[0]
             tg, ig, ng = gpu_trace(t, rays)
             assert np.array_equal(tg, tb) and np.array_equal(ig, ib)
             hit = ib >= 0
@@ -336,7 +340,11 @@ def test_upload_time_optimisation_keeps_hits_and_lowers_the_cost(scene):
             acc.free()
             rgba.free()
             assert int(np.any(got != ref, axis=-1).sum()) <= 2
-        print(f"{scene}: area cost in node visits {costs[0]:.3f} -> {costs[2]:.3f}")
-        assert costs[2] < costs[0]
+            if rebuild == 1:
+                assert t.last_build_ms() > 0          # a device build stands behind the tree, optimised or not
+        print(f"{scene}: area cost in node visits, uploaded {costs[(0, 0)]:.3f} -> optimised {costs[(0, 2)]:.3f}; re-clustered {costs[(1, 0)]:.3f} "
+              f"-> optimised {costs[(1, 2)]:.3f}; PT_OPT_REBUILD 2 keeps {costs[(2, 2)]:.3f}")
+        assert costs[(0, 2)] < costs[(0, 0)] and costs[(1, 2)] < costs[(1, 0)]
+        assert costs[(2, 2)] == min(costs[(0, 2)], costs[(1, 2)])
     finally:
         t.close()
