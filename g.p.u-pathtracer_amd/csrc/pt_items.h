@@ -21,7 +21,8 @@ __host__ __device__ inline void pt_encode_record(const float* v0, const float* v
     rec[12] = fmaf(ay, bz, -(az * by)); rec[13] = fmaf(az, bx, -(ax * bz)); rec[14] = fmaf(ax, by, -(ay * bx)); rec[15] = 0.f;
 }
 
-// 4-wide node: origin = the children's common lower corner, one power-of-two scale per axis,
+// 4-wide node: origin = the children's common lower corner, one grid step per axis (ext / 255 and a hair: round 3; a power of
+// two in rounds 1-2, which made the grid up to twice as coarse as it had to be),
 // child planes as bytes rounded OUTWARD (checked with the walk's own fma(q, scale, origin)), so a
 // decoded child box always contains the exact one:
 //   d[0..2] origin   d[3], d[14], d[15] = the scales of x, y, z as floats (2^e: the walk multiplies
@@ -43,6 +44,7 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
     for (int a = 0; a < 3; a++) {
         const float origin = nb.lo[a];
         const float ext = nb.hi[a] - nb.lo[a];
+#ifdef PT_WIDE_SCALE_POW2   // rounds 1-2: the grid step is the next power of two >= ext / 255 (up to twice as coarse as needed)
         int e = 1;
         if (ext > 0.f) {
             int x;
@@ -52,6 +54,16 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
         e = e > 254 ? 254 : (e < 1 ? 1 : e);
         while (e < 254 && fmaf(255.f, pt_i2f(e << 23), origin) < nb.hi[a]) e++;
         const float scale = pt_i2f(e << 23);
+#else
+        // the grid step: ext / 255 with a relative margin of 2^-18 (the walk multiplies it by 1/dir before it multiplies by q:
+        // two roundings of 2^-24 each stay far inside), raised until plane 255 reaches the node's upper bound in binary32
+        float scale = pt_i2f(1 << 23);   // a flat node: the smallest normal step
+        if (ext > 0.f) {
+            scale = (float)(((double)ext / 255.0) * (1.0 + 1.0 / 262144.0));
+            if (!(scale >= pt_i2f(1 << 23))) scale = pt_i2f(1 << 23);
+            while (fmaf(255.f, scale, origin) < nb.hi[a]) scale = scale * (1.0f + 1.0f / 65536.0f);
+        }
+#endif
         scales[a] = scale;
         for (int k = 0; k < 4; k++) {
             int qlo = 255, qhi = 0;

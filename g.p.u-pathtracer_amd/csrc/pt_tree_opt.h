@@ -145,4 +145,7 @@ inline size_t reinsertion_pass(Tree& T, size_t max_visits = 4096) {
     return moved;
 }
 
+// (The paper's finer move — dissolve an inner node and re-insert its two children separately — was tried on top of these passes:
+// cornell_dragon_800k 24.13 -> 23.86 in inner-node area cost after two more passes, and not monotone; not kept.)
+
 }  // namespace pttreeopt
