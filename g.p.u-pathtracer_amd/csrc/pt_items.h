@@ -25,7 +25,7 @@ __host__ __device__ inline void pt_encode_record(const float* v0, const float* v
 // two in rounds 1-2, which made the grid up to twice as coarse as it had to be),
 // child planes as bytes rounded OUTWARD (checked with the walk's own fma(q, scale, origin)), so a
 // decoded child box always contains the exact one:
-//   d[0..2] origin   d[3], d[14], d[15] = the scales of x, y, z as floats (2^e: the walk multiplies
+//   d[0..2] origin   d[3], d[14], d[15] = the grid steps of x, y, z as floats (the walk multiplies
 //   them by 1/dir without decoding anything)
 //   d[4..6] lo bytes of x, y, z (child k in byte k)   d[7], d[8], d[9] hi bytes of x, y, z
 //   d[10..13] links of children 0..3
@@ -44,17 +44,6 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
     for (int a = 0; a < 3; a++) {
         const float origin = nb.lo[a];
         const float ext = nb.hi[a] - nb.lo[a];
-#ifdef PT_WIDE_SCALE_POW2   // rounds 1-2: the grid step is the next power of two >= ext / 255 (up to twice as coarse as needed)
-        int e = 1;
-        if (ext > 0.f) {
-            int x;
-            (void)frexp((double)ext / 255.0, &x);  // ext/255 = m 2^x, m in [0.5,1) => 2^x >= ext/255
-            e = x + 127;
-        }
-        e = e > 254 ? 254 : (e < 1 ? 1 : e);
-        while (e < 254 && fmaf(255.f, pt_i2f(e << 23), origin) < nb.hi[a]) e++;
-        const float scale = pt_i2f(e << 23);
-#else
         // the grid step: ext / 255 with a relative margin of 2^-18 (the walk multiplies it by 1/dir before it multiplies by q:
         // two roundings of 2^-24 each stay far inside), raised until plane 255 reaches the node's upper bound in binary32
         float scale = pt_i2f(1 << 23);   // a flat node: the smallest normal step
@@ -63,7 +52,6 @@ __host__ __device__ inline void pt_encode_wide_node(const PtBox* cb, int n, cons
             if (!(scale >= pt_i2f(1 << 23))) scale = pt_i2f(1 << 23);
             while (fmaf(255.f, scale, origin) < nb.hi[a]) scale = scale * (1.0f + 1.0f / 65536.0f);
         }
-#endif
         scales[a] = scale;
         for (int k = 0; k < 4; k++) {
             int qlo = 255, qhi = 0;
