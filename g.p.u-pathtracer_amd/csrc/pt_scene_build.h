@@ -282,11 +282,9 @@ inline bool optimize(Tree& T, int passes, uint32_t max_depth, double& cost_befor
         }
     }
     cost_before = cost_after = O.cost();
-    for (int p = 0; p < passes; p++) {
-        const size_t moved = pttreeopt::reinsertion_pass(O);
-        if (moved == 0) break;
-    }
-    if (O.depth() > max_depth) return false;
+    const size_t n_nodes = O.box.size();
+    (void)pttreeopt::optimise(O, passes);
+    if (!pttreeopt::intact(O, n_nodes) || O.depth() > max_depth) return false;   // (never seen: the caller then emits the tree as it came)
     cost_after = O.cost();
     // back to BNodes: the root must be nodes[0]; inner nodes are renumbered in the order they are met
     std::vector<BNode> out;

@@ -14,8 +14,10 @@
 // cornell_dragon-100k 7.33 -> 7.05 ms, gto_sixteen 6.36 -> 6.31, dragon 5.31 -> 5.34 (flat).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <limits>
+#include <thread>
 #include <vector>
 
 namespace pttreeopt {
@@ -86,63 +88,206 @@ struct Tree {
     }
 };
 
-// one pass over every node but the root and its children; returns how many found a better place.  max_visits caps one search.
-inline size_t reinsertion_pass(Tree& T, size_t max_visits = 4096) {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A pass runs in parallel batches.  The search is the expensive part and reads only: for a batch of nodes (consecutive in the
+// area order; small batches for the large nodes at the top, growing towards the leaves) every thread finds its node's best place
+// on the tree AS IT STANDS, with the node taken out VIRTUALLY — the boxes of its ancestors are re-fitted in a side table (at most
+// one entry per level) and its parent stands for the sibling that would move up.  The moves are then carried out one after the
+// other, each priced again on the tree as it is by then against staying put (apply_move), so the cost never rises.  Measured
+// against the strictly serial pass (take out, search, put back, node by node: 5 s per pass and million nodes), 800 k scene,
+// inner-node area cost from 30.66: serial 24.94 / 24.13 after 1 / 2 passes; batched 26.27 / 24.51 / 24.05 after 1 / 2 / 3 passes at
+// 1.3 s per pass on 8 threads — three batched passes replace two serial ones.
+struct SearchScratch {
+    std::vector<uint8_t> mark;         // node -> index into path (255 = not on the path)
+    int path_node[72];
+    Box6 path_box[72];
+    float path_area[72];
+    int n_path = 0;
+    struct Cand { float induced; int node; };
+    std::vector<Cand> heap;
+};
+
+// best sibling for L with L (and its parent) taken out virtually; -1: leave it
+inline int find_place(const Tree& T, int L, size_t max_visits, SearchScratch& sc) {
+    const int P = T.parent[L];
+    if (P < 0) return -1;
+    const int G = T.parent[P];
+    if (G < 0) return -1;
+    const int S = T.c0[P] == L ? T.c1[P] : T.c0[P];
+    if (sc.mark.size() != T.box.size()) sc.mark.assign(T.box.size(), 255);
+    // ancestors re-fitted without L: G's child P is replaced by S
+    sc.n_path = 0;
+    {
+        Box6 below = T.box[S];
+        int from = P, a = G;
+        while (a >= 0 && sc.n_path < 72) {
+            const int other = T.c0[a] == from ? T.c1[a] : T.c0[a];
+            Box6 b = below;
+            b.grow(T.box[other]);
+            if (b.same(T.box[a])) break;          // nothing changes from here up
+            sc.path_node[sc.n_path] = a; sc.path_box[sc.n_path] = b; sc.path_area[sc.n_path] = b.area();
+            sc.mark[(size_t)a] = (uint8_t)sc.n_path;
+            sc.n_path++;
+            below = b;
+            from = a;
+            a = T.parent[a];
+        }
+    }
+    auto worse = [](const SearchScratch::Cand& x, const SearchScratch::Cand& y) { return x.induced > y.induced || (x.induced == y.induced && x.node > y.node); };
+    const Box6 lb = T.box[L];
+    const float la = T.area[L];
+    float best_cost = std::numeric_limits<float>::max();
+    int best = S;
+    sc.heap.clear();
+    sc.heap.push_back({0.f, T.root});
+    size_t visits = 0;
+    while (!sc.heap.empty()) {
+        std::pop_heap(sc.heap.begin(), sc.heap.end(), worse);
+        SearchScratch::Cand cnd = sc.heap.back();
+        sc.heap.pop_back();
+        if (cnd.induced + la >= best_cost) break;
+        int X = cnd.node == P ? S : cnd.node;             // P is out: its sibling child stands in its place
+        const uint8_t m = sc.mark[(size_t)X];
+        Box6 u = m != 255 ? sc.path_box[m] : T.box[X];
+        const float xa = m != 255 ? sc.path_area[m] : T.area[X];
+        u.grow(lb);
+        const float total = cnd.induced + u.area();
+        if (total < best_cost) { best_cost = total; best = X; }
+        if (++visits >= max_visits) break;
+        const float ind_child = total - xa;
+        if (!T.leaf(X) && ind_child + la < best_cost) {
+            sc.heap.push_back({ind_child, T.c0[X]});
+            std::push_heap(sc.heap.begin(), sc.heap.end(), worse);
+            sc.heap.push_back({ind_child, T.c1[X]});
+            std::push_heap(sc.heap.begin(), sc.heap.end(), worse);
+        }
+    }
+    for (int k = 0; k < sc.n_path; k++) sc.mark[(size_t)sc.path_node[k]] = 255;
+    return best == S ? -1 : best;
+}
+
+// what inserting a subtree with box lb beside X costs on the tree as it stands: area(X u lb) + the growth of X's ancestors
+inline float insertion_cost(const Tree& T, int X, const Box6& lb) {
+    Box6 u = T.box[X];
+    u.grow(lb);
+    float cost = u.area();
+    for (int a = T.parent[X]; a >= 0; a = T.parent[a]) {
+        Box6 g = T.box[a];
+        g.grow(lb);
+        const float grown = g.area() - T.area[a];
+        if (!(grown > 0.f)) break;                  // this ancestor already holds lb: so do all above it
+        cost += grown;
+    }
+    return cost;
+}
+
+// carries out one move found by find_place on an EARLIER state of the tree: L is taken out for real, the target X is priced again on
+// the tree as it is NOW against putting L back beside its old sibling, and L goes where it is cheaper — a stale move can no longer
+// raise the cost.  Returns true when L ended up somewhere new.
+inline bool apply_move(Tree& T, int L, int X) {
+    const int P = T.parent[L];
+    if (P < 0 || X < 0 || X == L) return false;
+    const int G = T.parent[P];
+    if (G < 0) return false;
+    const int S = T.c0[P] == L ? T.c1[P] : T.c0[P];
+    if (X == P) X = S;
+    if (X == S) return false;
+    for (int a = X; a >= 0; a = T.parent[a]) if (a == L) return false;   // the target sits inside the subtree that moves
+    T.replace_child(G, P, S);
+    T.parent[S] = G;
+    T.refit_up(G);
+    const Box6 lb = T.box[L];
+    const bool better = insertion_cost(T, X, lb) < insertion_cost(T, S, lb);
+    if (!better) X = S;
+    const int XP = T.parent[X];
+    if (XP >= 0) T.replace_child(XP, X, P); else T.root = P;
+    T.parent[P] = XP;
+    T.c0[P] = X; T.c1[P] = L;
+    T.parent[X] = P; T.parent[L] = P;
+    Box6 pb = T.box[X];
+    pb.grow(lb);
+    T.box[P] = pb; T.area[P] = pb.area();
+    T.refit_up(XP);
+    return better;
+}
+
+// run(n_items, fn(begin, end, thread)) must call fn over disjoint ranges covering [0, n_items) from up to n_threads threads and
+// return when all are done (the callers bring their own threads: std::thread in libptmi, OpenMP in libpthost)
+template <class ParallelFor>
+inline size_t reinsertion_pass_batched(Tree& T, int n_threads, ParallelFor&& run, size_t max_visits = 4096) {
     const int n = (int)T.box.size();
     std::vector<int> order;
     order.reserve((size_t)n);
     for (int i = 0; i < n; i++) if (i != T.root) order.push_back(i);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return T.area[a] > T.area[b] || (T.area[a] == T.area[b] && a < b); });
-    struct Cand { float induced; int node; };
-    auto worse = [](const Cand& a, const Cand& b) { return a.induced > b.induced || (a.induced == b.induced && a.node > b.node); };
-    std::vector<Cand> heap;
+    std::vector<SearchScratch> scratch((size_t)std::max(1, n_threads));
+    std::vector<int> target(order.size(), -1);
     size_t moved = 0;
-    for (int L : order) {
-        const int P = T.parent[L];
-        if (P < 0) continue;                        // became the root meanwhile
-        const int S = T.c0[P] == L ? T.c1[P] : T.c0[P];
-        const int G = T.parent[P];
-        if (G < 0) continue;                        // a child of the root: the top stays
-        T.replace_child(G, P, S);                   // take L (and P) out: S moves up
-        T.parent[S] = G;
-        T.refit_up(G);
-        const Box6 lb = T.box[L];
-        const float la = T.area[L];
-        float best_cost = std::numeric_limits<float>::max();
-        int best = S;
-        heap.clear();
-        heap.push_back({0.f, T.root});
-        size_t visits = 0;
-        while (!heap.empty()) {
-            std::pop_heap(heap.begin(), heap.end(), worse);
-            const Cand cnd = heap.back();
-            heap.pop_back();
-            if (cnd.induced + la >= best_cost) break;   // the heap is ordered by induced cost: nothing left can beat the best
-            Box6 u = T.box[cnd.node];
-            u.grow(lb);
-            const float total = cnd.induced + u.area();
-            if (total < best_cost) { best_cost = total; best = cnd.node; }
-            if (++visits >= max_visits) break;
-            const float ind_child = total - T.area[cnd.node];
-            if (!T.leaf(cnd.node) && ind_child + la < best_cost) {
-                heap.push_back({ind_child, T.c0[cnd.node]});
-                std::push_heap(heap.begin(), heap.end(), worse);
-                heap.push_back({ind_child, T.c1[cnd.node]});
-                std::push_heap(heap.begin(), heap.end(), worse);
-            }
-        }
-        const int X = best, XP = T.parent[X];          // put it back: P becomes the parent of (X, L)
-        if (XP >= 0) T.replace_child(XP, X, P); else T.root = P;
-        T.parent[P] = XP;
-        T.c0[P] = X; T.c1[P] = L;
-        T.parent[X] = P; T.parent[L] = P;
-        Box6 pb = T.box[X];
-        pb.grow(lb);
-        T.box[P] = pb; T.area[P] = pb.area();
-        T.refit_up(XP);
-        if (X != S) moved++;
+    // small batches at the top of the order (the large nodes, whose moves change the most), growing towards the leaves
+    size_t begin = 0, batch = 256;
+    while (begin < order.size()) {
+        const size_t end = std::min(order.size(), begin + batch);
+        run(end - begin, [&](size_t b, size_t e, int thread) {
+            SearchScratch& sc = scratch[(size_t)thread];
+            for (size_t k = b; k < e; k++) target[begin + k] = find_place(T, order[begin + k], max_visits, sc);
+        });
+        for (size_t k = begin; k < end; k++)
+            if (target[k] >= 0 && apply_move(T, order[k], target[k])) moved++;
+        begin = end;
+        batch = std::min<size_t>(batch * 2, 32768);
     }
     return moved;
+}
+
+// structural check of a tree that was re-arranged: every node reached exactly once from the root, parent / child links consistent
+inline bool intact(const Tree& T, size_t n_nodes_expected) {
+    std::vector<uint8_t> seen(T.box.size(), 0);
+    std::vector<int> st{T.root};
+    size_t n = 0;
+    if (T.root < 0 || (size_t)T.root >= T.box.size() || T.parent[T.root] != -1) return false;
+    while (!st.empty()) {
+        const int i = st.back();
+        st.pop_back();
+        if (i < 0 || (size_t)i >= T.box.size() || seen[(size_t)i]) return false;
+        seen[(size_t)i] = 1;
+        n++;
+        if (T.leaf(i)) continue;
+        const int a = T.c0[i], b = T.c1[i];
+        if (a < 0 || b < 0 || (size_t)a >= T.box.size() || (size_t)b >= T.box.size() || T.parent[a] != i || T.parent[b] != i) return false;
+        st.push_back(a);
+        st.push_back(b);
+    }
+    return n == n_nodes_expected;
+}
+
+// n passes with the machine's threads (std::thread: no OpenMP runtime needed where this header goes); the result is the same for
+// any number of threads (searches read a frozen tree, moves are carried out in order)
+inline size_t optimise(Tree& T, int passes, size_t max_visits = 4096) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = (int)std::min<unsigned>(std::max<unsigned>(hw, 1u), 64u);
+    auto run = [&](size_t n_items, auto fn) {
+        const size_t chunk = 16;
+        if (n_threads <= 1 || n_items <= 4 * chunk) { fn((size_t)0, n_items, 0); return; }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        th.reserve((size_t)n_threads);
+        for (int t = 0; t < n_threads; t++)
+            th.emplace_back([&, t] {
+                for (;;) {
+                    const size_t b = next.fetch_add(chunk);
+                    if (b >= n_items) break;
+                    fn(b, std::min(n_items, b + chunk), t);
+                }
+            });
+        for (std::thread& x : th) x.join();
+    };
+    size_t moved_total = 0;
+    for (int p = 0; p < passes; p++) {
+        const size_t moved = reinsertion_pass_batched(T, n_threads, run, max_visits);
+        moved_total += moved;
+        if (moved == 0) break;
+    }
+    return moved_total;
 }
 
 // (The paper's finer move — dissolve an inner node and re-insert its two children separately — was tried on top of these passes:

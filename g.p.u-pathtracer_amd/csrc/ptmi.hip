@@ -93,6 +93,69 @@ int stage_mark(pt_ctx* c, int kind) {
 }
 }  // namespace ptmi
 
+
+namespace ptmi {
+// refine (leaves of at most PT_OPT_LEAF_MAX references), optimise (PT_OPT_OPTIMIZE), emit, upload: the tree `X` becomes the context's
+static int install_tree(pt_ctx* c, ptscene::Tree& X, int32_t max_id) {
+    ptscene::refine(X, (uint32_t)c->opt_leaf_max);
+    c->opt_cost[0] = c->opt_cost[1] = 0.0;
+    if (c->opt_optimize > 0 && c->opt_tri_test == 0) {   // every node re-inserted where the area cost grows least (pt_tree_opt.h)
+        double before = 0.0, after = 0.0;
+        if (ptscene::optimize(X, c->opt_optimize, 64, before, after)) { c->opt_cost[0] = before; c->opt_cost[1] = after; }
+    }
+    ptscene::Output O;
+    ptscene::emit(X, PT_MAX_TOP, O, c->opt_tri_test == 1);
+    const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
+    if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
+    c->d_tris = nullptr;
+    c->has_bvh = false;
+    HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb + wb));
+    c->d_tris = c->d_nodes;  // one item buffer: links index it directly
+    HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
+    c->records_woop = c->opt_tri_test == 1;
+    c->wide_root = O.wide_root_f4;
+    c->wide_top_layout = O.n_top_wide;
+    c->wide_depth = O.depth_wide;
+    c->n_wide = O.wide.size() / 16;
+    c->n_top_layout = O.n_top_bin;
+    c->n_inner = O.bin.size() / 16;
+    c->n_refs = O.n_refs;
+    c->n_leaves = O.n_leaves;
+    c->max_depth = O.depth_bin;
+    c->scene_bytes = nb + tb + wb;
+    c->max_tri_id = max_id;
+    c->has_bvh = true;
+    c->build_ms = -1.f;   // no device build stands behind this tree (optimise_device_tree puts it back when one does)
+    c->scene_gen++;
+    return PT_OK;
+}
+
+// PT_OPT_OPTIMIZE on a tree the DEVICE built (pt_build_bvh, PT_OPT_REBUILD): binary nodes + the records' ids come back to the host, the
+// hierarchy is optimised like an uploaded one and installed in its place; the device build's time stays on the context.
+// by_id[id] = the nine vertex floats of triangle `id` (the caller's own: records are re-encoded from them bit for bit).
+static int optimise_device_tree(pt_ctx* c, const std::vector<const float*>& by_id, int32_t max_id) {
+    if (c->opt_optimize <= 0 || !c->has_bvh || c->records_woop) return PT_OK;
+    const size_t n_bin = (size_t)c->n_inner, n_rec = (size_t)c->n_refs;
+    std::vector<float> bin(16 * n_bin), rec(16 * n_rec);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(bin.data(), c->d_nodes, bin.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(rec.data(), (const char*)c->d_nodes + bin.size() * sizeof(float), rec.size() * sizeof(float), hipMemcpyDeviceToHost));
+    ptscene::Tree X;
+    std::string why;
+    if (!ptscene::from_items(bin.data(), n_bin, rec.data(), n_rec, by_id, X, why)) return fail(c, PT_ERR_DEVICE, "device-built tree: " + why);
+    const float device_ms = c->build_ms;
+    const int rc = install_tree(c, X, max_id);
+    if (rc == PT_OK) c->build_ms = device_ms;
+    return rc;
+}
+}  // namespace ptmi
+
 extern "C" {
 
 int pt_abi_version(void) { return PTMI_ABI_VERSION; }
@@ -339,62 +402,12 @@ int pt_upload_bvh(pt_ctx* c, const float* nodes, size_t n_node_vec4, const float
             rc = build_bvh_impl(c, verts.data(), verts.size() / 3, tri_rows.data(), ids.size(), 0, &too_deep, ids.data());
         return rc;
     };
-    // refine (leaves of at most PT_OPT_LEAF_MAX references), optimise (PT_OPT_OPTIMIZE), emit, upload: the tree `X` becomes the context's
-    auto install = [&](ptscene::Tree& X) -> int {
-        ptscene::refine(X, (uint32_t)c->opt_leaf_max);
-        c->opt_cost[0] = c->opt_cost[1] = 0.0;
-        if (c->opt_optimize > 0 && c->opt_tri_test == 0) {   // every node re-inserted where the area cost grows least (pt_tree_opt.h)
-            double before = 0.0, after = 0.0;
-            if (ptscene::optimize(X, c->opt_optimize, 64, before, after)) { c->opt_cost[0] = before; c->opt_cost[1] = after; }
-        }
-        ptscene::Output O;
-        ptscene::emit(X, PT_MAX_TOP, O, c->opt_tri_test == 1);
-        const size_t nb = O.bin.size() * sizeof(float), tb = O.rec.size() * sizeof(float), wb = O.wide.size() * sizeof(float);
-        if ((nb + tb + wb) / 16 >= (size_t)PT_SENTINEL) return fail(c, PT_ERR_INVALID, "pt_upload_bvh: scene too large for 32-bit links");
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->d_nodes); c->d_nodes = nullptr;
-        c->d_tris = nullptr;
-        c->has_bvh = false;
-        HIP_TRY(c, hipMalloc((void**)&c->d_nodes, nb + tb + wb));
-        c->d_tris = c->d_nodes;  // one item buffer: links index it directly
-        HIP_TRY(c, hipMemcpy(c->d_nodes, O.bin.data(), nb, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb, O.rec.data(), tb, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy((char*)c->d_nodes + nb + tb, O.wide.data(), wb, hipMemcpyHostToDevice));
-        c->records_woop = c->opt_tri_test == 1;
-        c->wide_root = O.wide_root_f4;
-        c->wide_top_layout = O.n_top_wide;
-        c->wide_depth = O.depth_wide;
-        c->n_wide = O.wide.size() / 16;
-        c->n_top_layout = O.n_top_bin;
-        c->n_inner = O.bin.size() / 16;
-        c->n_refs = O.n_refs;
-        c->n_leaves = O.n_leaves;
-        c->max_depth = O.depth_bin;
-        c->scene_bytes = nb + tb + wb;
-        c->max_tri_id = max_id;
-        c->has_bvh = true;
-        c->build_ms = -1.f;   // no device build stands behind this tree (the callers below put it back when one does)
-        c->scene_gen++;
-        return PT_OK;
-    };
-    // PT_OPT_REBUILD with PT_OPT_OPTIMIZE: the re-clustered hierarchy comes back from the device (binary nodes + the records' ids),
-    // is optimised like an uploaded one and installed in its place; the device build's time stays on the context
+    auto install = [&](ptscene::Tree& X) -> int { return install_tree(c, X, max_id); };
     auto optimise_reclustered = [&]() -> int {
-        if (c->opt_optimize <= 0 || !c->has_bvh || c->records_woop) return PT_OK;
-        const size_t n_bin = (size_t)c->n_inner, n_rec = (size_t)c->n_refs;
-        std::vector<float> bin(16 * n_bin), rec(16 * n_rec);
-        HIP_TRY(c, hipMemcpy(bin.data(), c->d_nodes, bin.size() * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(rec.data(), (const char*)c->d_nodes + bin.size() * sizeof(float), rec.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (c->opt_optimize <= 0) return PT_OK;
         std::vector<const float*> by_id((size_t)max_id + 1, nullptr);
         for (const ptscene::Ref& r : T.refs) if (!by_id[(size_t)r.id]) by_id[(size_t)r.id] = r.v;
-        ptscene::Tree X;
-        std::string why;
-        if (!ptscene::from_items(bin.data(), n_bin, rec.data(), n_rec, by_id, X, why)) return fail(c, PT_ERR_DEVICE, "pt_upload_bvh: re-clustered tree: " + why);
-        const float device_ms = c->build_ms;
-        const int rc = install(X);
-        if (rc == PT_OK) c->build_ms = device_ms;
-        return rc;
+        return optimise_device_tree(c, by_id, max_id);
     };
     if (rebuild == 1) {
         const int rc = recluster();
@@ -435,6 +448,15 @@ int pt_build_bvh(pt_ctx* c, const float* verts, size_t n_verts, const int32_t* t
     // PLOC on degenerate input (hundreds of identical boxes: one merge per round, a chain): the Karras
     // hierarchy separates equal keys by position and stays balanced
     if (rc != PT_OK && too_deep && c->opt_build_algo == 1) rc = build_bvh_impl(c, verts, n_verts, tris, n_tris, 0, &too_deep);
+    if (rc == PT_OK && c->opt_optimize > 0 && c->opt_presplit == 0) {   // PT_OPT_OPTIMIZE: the built hierarchy goes through the host optimiser
+        std::vector<float> flat(9 * n_tris);
+        std::vector<const float*> by_id(n_tris);
+        for (size_t t = 0; t < n_tris; t++) {
+            for (int k = 0; k < 3; k++) std::memcpy(&flat[9 * t + 3 * (size_t)k], verts + 3 * (size_t)tris[3 * t + (size_t)k], 3 * sizeof(float));
+            by_id[t] = &flat[9 * t];
+        }
+        rc = optimise_device_tree(c, by_id, (int32_t)n_tris - 1);
+    }
     return rc;
 }
 

@@ -755,13 +755,11 @@ pth_bvh* pth_bvh_build(const pth_mesh* mesh, const pth_build_params* params) {
         OptBridge ob;
         ob.from(tree.get());
         opt_before = opt_after = ob.T.cost();
-        for (int pass = 0; pass < P.optimize_passes; pass++) {
-            const size_t moved = pttreeopt::reinsertion_pass(ob.T);
-            opt_after = ob.T.cost();
-            if (moved == 0) break;
-        }
-        if (ob.T.depth() <= (uint32_t)P.max_depth) tree = ob.to_nodes();   // else: keep the builder's tree (the Compact layout caps the depth)
-        else opt_after = opt_before;
+        const size_t n_nodes = ob.T.box.size();
+        (void)pttreeopt::optimise(ob.T, P.optimize_passes);
+        opt_after = ob.T.cost();
+        if (pttreeopt::intact(ob.T, n_nodes) && ob.T.depth() <= (uint32_t)P.max_depth) tree = ob.to_nodes();
+        else opt_after = opt_before;   // keep the builder's tree (the Compact layout caps the depth)
     }
 
     if (tree->leaf()) {  // wrap a root leaf (CudaBVH.cpp:141 asserts)

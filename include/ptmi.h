@@ -177,14 +177,15 @@ enum {
                                  DESIGN.md 5.5) — the caller's on architectural scenes with long triangles
                                  that its spatial splits cut, the re-clustered one on dense scans; costs one
                                  device build (7 ms for 800 k triangles) per upload.  Default 0           */
-    PT_OPT_OPTIMIZE = 24,     /* pt_upload_bvh: 0 (default) = walk the caller's hierarchy as it is (after PT_OPT_LEAF_MAX); n > 0 =
-                                 n passes of insertion-based optimisation over it first (Bittner et al. 2013: every node is taken
-                                 out and re-inserted where the tree's surface-area cost grows least; csrc/pt_tree_opt.h) — on
-                                 the host, ~5 s per pass and million nodes, two passes get nearly all there is.  Same closest
-                                 hits (grazing cases as PT_OPT_REBUILD).  cornell_dragon_800k, the host SBVH tree: area cost in
-                                 node visits 14.4 -> 12.6, bench step 9.65 -> 9.00 ms (the device's PLOC tree: 12.75 /
-                                 9.26 ms; a host tree built without spatial splits: 11.7 / 8.87 ms).  With PT_OPT_REBUILD 2
-                                 the optimised hierarchy competes with the re-clustered one                          */
+    PT_OPT_OPTIMIZE = 24,     /* pt_upload_bvh / pt_build_bvh: 0 (default) = walk the hierarchy as it comes (after PT_OPT_LEAF_MAX); n > 0 = n
+                                 passes of insertion-based optimisation over it first (Bittner et al. 2013: every node is taken out
+                                 and re-inserted where the tree's surface-area cost grows least; csrc/pt_tree_opt.h) — on the host's
+                                 threads, ~0.2 s per pass and million nodes on 64 threads; three passes get nearly all there is.  Same
+                                 closest hits (grazing cases as PT_OPT_REBUILD).  A device-built tree (pt_build_bvh, PT_OPT_REBUILD)
+                                 is fetched back, optimised and installed again.  cornell_dragon_800k: area cost in node visits /
+                                 bench step, host SBVH tree 14.4 / 9.65 ms -> 12.6 / 9.00; host SAH tree without spatial splits
+                                 14.6 / 9.95 -> 11.7 / 8.87; the device's PLOC tree 12.75 / 9.26 -> 12.1 / 9.15.  With
+                                 PT_OPT_REBUILD 2 the two optimised hierarchies compete                                         */
     PT_OPT_PRESPLIT = 18,     /* pt_build_bvh / PT_OPT_REBUILD: 0 (default) = off; v > 0 = triangles longer than
                                  v per cent of (scene diagonal / sqrt(n triangles)) enter the builder as up
                                  to 8 primitives, one per slab of their box (early split clipping)      */

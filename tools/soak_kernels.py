@@ -32,7 +32,8 @@ for r in range(a.rounds):
     cam = g.default_camera(max(W, 61), max(H, 61))
     cam.aspect = W / H
     res = {}
-    source = ["host tree", "host tree, rebuilt on the device", "device PLOC", "device LBVH"][int(rng.integers(0, 4))]
+    source = ["host tree", "host tree, rebuilt on the device", "device PLOC", "device LBVH", "host tree, optimised at upload",
+              "host tree, rebuilt on the device and optimised"][int(rng.integers(0, 6))]
     for name, pt in pts.items():
         # the reference kernel (persistent) always walks the host tree; the others a randomly chosen tree
         src = "host tree" if name == "persistent" else source
@@ -40,6 +41,11 @@ for r in range(a.rounds):
             pt.upload_bvh(scenes[scene])
         elif src == "host tree, rebuilt on the device":
             pt.set_option(g.OPT_REBUILD, 1); pt.upload_bvh(scenes[scene]); pt.set_option(g.OPT_REBUILD, 0)
+        elif src == "host tree, optimised at upload":
+            pt.set_option(g.OPT_OPTIMIZE, 2); pt.upload_bvh(scenes[scene]); pt.set_option(g.OPT_OPTIMIZE, 0)
+        elif src == "host tree, rebuilt on the device and optimised":
+            pt.set_option(g.OPT_OPTIMIZE, 2); pt.set_option(g.OPT_REBUILD, 1); pt.upload_bvh(scenes[scene])
+            pt.set_option(g.OPT_REBUILD, 0); pt.set_option(g.OPT_OPTIMIZE, 0)
         else:
             pt.set_option(g.OPT_BUILD_ALGO, 1 if src == "device PLOC" else 0)
             pt.build_bvh(meshes[scene])

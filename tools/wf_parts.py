@@ -43,7 +43,10 @@ if occ is not None:
     pt.set_option(g.OPT_OCCUPANCY, occ)
 t0 = time.perf_counter()
 if dev_build:
+    pt.set_option(g.OPT_OPTIMIZE, optimize)
     pt.build_bvh(mesh)
+    pt.set_option(g.OPT_OPTIMIZE, 0)
+    print(f"device build (+ PT_OPT_OPTIMIZE {optimize}) {time.perf_counter() - t0:.1f} s", flush=True)
 else:
     bvh = g.Bvh(mesh, split_alpha=-1.0) if no_splits else g.Bvh(mesh, **bvh_kw)
     t1 = time.perf_counter()
