@@ -43,6 +43,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+OPT_PASSES = 4         # PT_OPT_OPTIMIZE passes at upload (csrc/pt_tree_opt.h; the batched passes converge by the fourth)
 KERNEL_NAMES = {0: "auto", 1: "mega", 3: "persistent", 5: "wavefront"}
 
 
@@ -70,6 +71,7 @@ def parse():
     ap.add_argument("--no-cpu-reference", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (materials, 1 spp, device tree, big scene, gather bound)")
     ap.add_argument("--device-build", action="store_true", help="build the BVH on the device (pt_build_bvh) instead of the host SBVH builder")
+    ap.add_argument("--device-optimize", type=int, default=0, help="with --device-build: PT_OPT_OPTIMIZE passes over the device-built tree")
     ap.add_argument("--host-splits", action="store_true", help="host tree with the builder's spatial splits (the reference's splitAlpha = 1e-5)")
     ap.add_argument("--keep-hierarchy", action="store_true",
                     help="PT_OPT_REBUILD 0: walk the uploaded hierarchy whatever it costs (default: PT_OPT_REBUILD 2, the upload also "
@@ -296,13 +298,17 @@ def main():
         pt.set_option(g.OPT_WAVE_BATCH, a.batch)
     tree_note = "built on the device (pt_build_bvh, PLOC)"
     if a.device_build:
+        pt.set_option(g.OPT_OPTIMIZE, a.device_optimize)
         pt.build_bvh(mesh)
+        pt.set_option(g.OPT_OPTIMIZE, 0)
+        if a.device_optimize:
+            tree_note += f", then PT_OPT_OPTIMIZE {a.device_optimize} on the host"
     else:
-        # the reference's flow: hierarchy built on the host (SBVH port), flattened, uploaded.  PT_OPT_OPTIMIZE 2: the upload first
-        # re-inserts every node of the caller's hierarchy where the area cost grows least (two passes, on the host, outside every
-        # timed region — the reference's own builder takes longer); PT_OPT_REBUILD 2: it also re-clusters the triangles on the
-        # device and keeps whichever hierarchy is cheaper to walk
-        pt.set_option(g.OPT_OPTIMIZE, 0 if a.keep_hierarchy else 2)
+        # the reference's flow: hierarchy built on the host (SBVH port), flattened, uploaded.  PT_OPT_OPTIMIZE: the upload first
+        # re-inserts every node of the caller's hierarchy where the area cost grows least (OPT_PASSES passes on the host's threads,
+        # 2-3 s, outside every timed region — the reference's own builder takes longer); PT_OPT_REBUILD 2: it also re-clusters the
+        # triangles on the device, optimises that tree too, and keeps whichever hierarchy is cheaper to walk
+        pt.set_option(g.OPT_OPTIMIZE, 0 if a.keep_hierarchy else OPT_PASSES)
         pt.set_option(g.OPT_REBUILD, 0 if a.keep_hierarchy else 2)
         t_up = time.perf_counter()
         pt.upload_bvh(bvh)
@@ -311,7 +317,7 @@ def main():
         pt.set_option(g.OPT_OPTIMIZE, 0)
         host_kind = "host SBVH hierarchy" if a.host_splits else "host SAH hierarchy (no spatial splits)"
         tree_note = (f"{host_kind}, uploaded as built (PT_OPT_OPTIMIZE 0, PT_OPT_REBUILD 0)" if a.keep_hierarchy else
-                     f"{host_kind} uploaded with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2 ({t_up:.1f} s): kept " +
+                     f"{host_kind} uploaded with PT_OPT_OPTIMIZE {OPT_PASSES} + PT_OPT_REBUILD 2 ({t_up:.1f} s): kept " +
                      ("the device's re-clustered tree, optimised" if pt.last_build_ms() > 0 else "the uploaded hierarchy, optimised"))
     pt.upload_spheres(sph)
     info = pt.scene_info()
@@ -706,7 +712,11 @@ def main():
         # ~0.8 GB > 256 MiB, tree built on the device; same camera / room / spp.  Not the headline.
         try:
             big = g.scene_mesh("cornell_dragon_6400k")
+            pt.set_option(g.OPT_OPTIMIZE, 0 if a.keep_hierarchy else 3)   # the device's tree through the optimiser (~20 s for 7.8 M nodes)
+            t_big = time.perf_counter()
             b_ms = pt.build_bvh(big)
+            t_big = time.perf_counter() - t_big
+            pt.set_option(g.OPT_OPTIMIZE, 0)
             binfo = pt.scene_info()
             settle()
             n_b = max(3, a.steps // 10)
@@ -730,6 +740,7 @@ def main():
             b_req = (b_items * 64.0 + b_stream) / b_launches
             out["big_scene"] = {"workload": f"cornell_dragon_6400k ({big.n_tris} tris) {W}x{H} depth {a.depth} {a.mat} + sphere room, {a.spp} spp per step",
                                 "device_mb": round(binfo["device_bytes"] / 2 ** 20, 1), "device_build_ms": round(b_ms, 1),
+                                "tree": f"built on the device (PLOC), then PT_OPT_OPTIMIZE 3 on the host: {t_big:.1f} s in all",
                                 "mrays_per_s": round(bc["rays"] * n_b / dtb / 1e6, 1), "ms_per_step": round(dtb / n_b * 1e3, 3),
                                 "stage_ms": {k: round(v, 3) for k, v in bst.items() if v > 0},
                                 "items_per_ray": round(b_items / bc["rays"], 2)}
@@ -742,7 +753,7 @@ def main():
             trb = None
             if not a.no_pmc:
                 try:
-                    trb = pmc_live(b_kname, ["--scene", "cornell_dragon_6400k", "--device-build", "--width", str(W), "--height", str(H), "--spp", str(a.spp),
+                    trb = pmc_live(b_kname, ["--scene", "cornell_dragon_6400k", "--device-build", "--device-optimize", "3", "--width", str(W), "--height", str(H), "--spp", str(a.spp),
                                              "--depth", str(a.depth), "--mat", a.mat, "--kernel", str(g.KERNEL_WAVEFRONT if bdom == "extend" else g.KERNEL_PERSISTENT)])
                 except Exception as e:
                     rb["pmc_live_error"] = str(e)[:120]
@@ -767,7 +778,8 @@ def main():
                                         "table_mb": round(gb["table_bytes"] / 2 ** 20, 1)}
                 rb["frac_of_gather_ceiling"] = round(b_items / b_launches / (b_kms * 1e-3) / gb["items_per_s_l2_resident"], 4)
                 rb["over_uniform_gather_rate"] = round(b_items / b_launches / (b_kms * 1e-3) / gb["items_per_s"], 4)
-            rb["note"] = "same fields as `roofline`, for cornell_dragon_6400k (1.2 GB of items: beyond the 256 MB Infinity Cache); the tree is the device builder's"
+            rb["note"] = ("same fields as `roofline`, for cornell_dragon_6400k (0.75-1.2 GB of items: beyond the 256 MB Infinity Cache); "
+                          "the tree is the device builder's, optimised on the host")
             out["roofline_hbm_scene"] = rb
             # in-run parity of this workload: one frame of `--big-parity-spp` samples over the DEVICE tree against the oracle's walk
             # over a HOST tree of the same mesh (checker, after every timed region), + a ray batch against brute force

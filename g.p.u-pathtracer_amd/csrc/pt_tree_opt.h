@@ -183,16 +183,17 @@ inline float insertion_cost(const Tree& T, int X, const Box6& lb) {
 
 // carries out one move found by find_place on an EARLIER state of the tree: L is taken out for real, the target X is priced again on
 // the tree as it is NOW against putting L back beside its old sibling, and L goes where it is cheaper — a stale move can no longer
-// raise the cost.  Returns true when L ended up somewhere new.
-inline bool apply_move(Tree& T, int L, int X) {
+// raise the cost.  Returns 1 when L ended up somewhere new, 0 when there was nothing to do, -1 when the move had gone stale (the
+// caller may search again on the tree as it is now).
+inline int apply_move(Tree& T, int L, int X) {
     const int P = T.parent[L];
-    if (P < 0 || X < 0 || X == L) return false;
+    if (P < 0 || X < 0 || X == L) return 0;
     const int G = T.parent[P];
-    if (G < 0) return false;
+    if (G < 0) return 0;
     const int S = T.c0[P] == L ? T.c1[P] : T.c0[P];
     if (X == P) X = S;
-    if (X == S) return false;
-    for (int a = X; a >= 0; a = T.parent[a]) if (a == L) return false;   // the target sits inside the subtree that moves
+    if (X == S) return 0;
+    for (int a = X; a >= 0; a = T.parent[a]) if (a == L) return -1;   // the target sits inside the subtree that moves
     T.replace_child(G, P, S);
     T.parent[S] = G;
     T.refit_up(G);
@@ -208,7 +209,7 @@ inline bool apply_move(Tree& T, int L, int X) {
     pb.grow(lb);
     T.box[P] = pb; T.area[P] = pb.area();
     T.refit_up(XP);
-    return better;
+    return better ? 1 : -1;
 }
 
 // run(n_items, fn(begin, end, thread)) must call fn over disjoint ranges covering [0, n_items) from up to n_threads threads and
@@ -231,8 +232,12 @@ inline size_t reinsertion_pass_batched(Tree& T, int n_threads, ParallelFor&& run
             SearchScratch& sc = scratch[(size_t)thread];
             for (size_t k = b; k < e; k++) target[begin + k] = find_place(T, order[begin + k], max_visits, sc);
         });
-        for (size_t k = begin; k < end; k++)
-            if (target[k] >= 0 && apply_move(T, order[k], target[k])) moved++;
+        for (size_t k = begin; k < end; k++) {
+            if (target[k] < 0) continue;
+            int r = apply_move(T, order[k], target[k]);
+            if (r < 0) r = apply_move(T, order[k], find_place(T, order[k], max_visits, scratch[0]));   // gone stale: once more, on the tree as it is now
+            if (r > 0) moved++;
+        }
         begin = end;
         batch = std::min<size_t>(batch * 2, 32768);
     }

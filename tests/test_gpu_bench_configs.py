@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=["default", "cheaper-tree", "wavefront", "persistent"])
 def ptd(request):
-    """default = whatever PT_KERNEL_AUTO picks; cheaper-tree = the same with PT_OPT_OPTIMIZE 2 + PT_OPT_REBUILD 2 over a host tree
+    """default = whatever PT_KERNEL_AUTO picks; cheaper-tree = the same with PT_OPT_OPTIMIZE 4 + PT_OPT_REBUILD 2 over a host tree
     built without spatial splits, which is what bench.py times (the upload optimises the caller's hierarchy by re-insertion,
     re-clusters the triangles on the device and optimises that too, and keeps whichever hierarchy costs fewer node visits);
     the two stage layouts named too."""
@@ -29,7 +29,7 @@ def ptd(request):
     elif request.param == "persistent":
         t.set_option(g.OPT_KERNEL, g.KERNEL_PERSISTENT)
     elif request.param == "cheaper-tree":
-        t.set_option(g.OPT_OPTIMIZE, 2)
+        t.set_option(g.OPT_OPTIMIZE, 4)
         t.set_option(g.OPT_REBUILD, 2)
     t.variant = request.param
     # bench.py's host tree is built without spatial splits (with PT_OPT_OPTIMIZE they no longer pay on its scene): the variant that
@@ -249,7 +249,8 @@ def test_rebuilt_800k_tree_against_uploaded_and_brute_force():
 
 
 def test_big_scene_6400k_parity():
-    """bench.py's HBM-resident workload (cornell + 64 dragons, 6.4 M triangles, 1.2 GB of items, tree built ON the device):
+    """bench.py's HBM-resident workload (cornell + 64 dragons, 6.4 M triangles, tree built ON the device and passed through the
+    hierarchy optimiser, 0.75 GB of items):
     (1) 200k incoherent rays + the primary rays of a 480x270 frame: (t, id, normal) == the brute-force oracle bit for bit;
     (2) one 1920x1080 frame, 2 spp, against the oracle's walk over the HOST tree of the same mesh: L2 < 1e-3, and every
     differing pixel arbitrated by brute force."""
@@ -257,10 +258,12 @@ def test_big_scene_6400k_parity():
     mesh = g.scene_mesh("cornell_dragon_6400k")
     t = g.PathTracer(0)
     try:
+        t.set_option(g.OPT_OPTIMIZE, 3)
         ms = t.build_bvh(mesh)
+        t.set_option(g.OPT_OPTIMIZE, 0)
         info = t.scene_info()
-        print(f"6400k: device build {ms:.1f} ms, {info}")
-        assert info["device_bytes"] > 2 ** 30 and info["n_tri_refs"] == mesh.n_tris
+        print(f"6400k: device build {ms:.1f} ms (+ PT_OPT_OPTIMIZE 3 on the host), {info}")
+        assert info["device_bytes"] > 700e6 and info["n_tri_refs"] == mesh.n_tris
         lo, hi = mesh.bounds()
         cam = g.default_camera(480, 270)
         rays = np.concatenate([orc.random_rays(6000, lo, hi, seed=77), orc.primary_rays(cam, 480, 270, frame=3)[::40]])
