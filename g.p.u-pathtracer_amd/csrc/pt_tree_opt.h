@@ -9,9 +9,10 @@
 // Putting it back beside its old sibling is one of the candidates, so the cost never rises.  Leaves stay what they are and keep
 // their (possibly clipped) boxes; ancestors' boxes are unions of their children's, so every hit stays reachable: the closest
 // hit of any ray is unchanged (tests/test_host_and_abi.py: the oracle's walk over optimised trees == brute force).
-// Measured (profiles/r03_tree_opt.txt), two passes at upload: cornell_dragon_800k host SBVH tree: area cost in node visits 14.4 -> 12.6,
-// bench step 9.65 -> 9.00 ms (the device's PLOC tree: 12.75 / 9.26 ms); built without spatial splits 11.7 / 8.87 ms;
-// cornell_dragon-100k 7.33 -> 7.05 ms, gto_sixteen 6.36 -> 6.31, dragon 5.31 -> 5.34 (flat).
+// Measured (profiles/r03_tree_opt.txt), area cost of the 4-wide tree in node visits / bench step: cornell_dragon_800k host SAH tree
+// without spatial splits 14.6 / 9.95 ms -> 11.7 / 8.8 ms (four passes, 2.5 s on the GPU box's host); the device's PLOC tree
+// 12.75 / 9.26 -> 11.9 / 9.1; host SBVH tree 14.4 / 9.65 -> 13.1 / 9.3 (12.6 / 9.0 with strictly serial passes);
+// cornell_dragon-100k 7.33 -> 7.05 ms, gto_sixteen 6.36 -> 6.31, dragon flat; the 6.4 M-triangle scene 38.6 / 19.6 -> 34.5 / 17.5 ms.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -213,7 +214,7 @@ inline int apply_move(Tree& T, int L, int X) {
 }
 
 // run(n_items, fn(begin, end, thread)) must call fn over disjoint ranges covering [0, n_items) from up to n_threads threads and
-// return when all are done (the callers bring their own threads: std::thread in libptmi, OpenMP in libpthost)
+// return when all are done (`optimise` below brings std::thread workers)
 template <class ParallelFor>
 inline size_t reinsertion_pass_batched(Tree& T, int n_threads, ParallelFor&& run, size_t max_visits = 4096) {
     const int n = (int)T.box.size();
