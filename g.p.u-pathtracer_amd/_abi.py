@@ -79,7 +79,7 @@ FLAG_NEE = 1 << 8
 FLAGS_SMALLPT = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RUSSIAN_ROULETTE | FLAG_MISS_KEEPS_PATH
 FLAGS_CPU_TRACER = FLAG_FACE_FORWARD | FLAG_COSINE_DIFF | FLAG_RR_CPU_TRACER | FLAG_MISS_KEEPS_PATH
 KERNEL_AUTO, KERNEL_MEGA_BVH2, KERNEL_PERSISTENT, KERNEL_WAVEFRONT = 0, 1, 3, 5
-OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT, OPT_WAVE_BLOCKS, OPT_OVERLAP, OPT_OPTIMIZE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 24
+OPT_KERNEL, OPT_COUNTERS, OPT_TIMING, OPT_BATCH, OPT_TOP_NODES, OPT_OCCUPANCY, OPT_LDS_STACK, OPT_WALK, OPT_LEAF_MAX, OPT_TRI_TEST, OPT_REFILL, OPT_VOTE_NODE, OPT_VOTE_REC, OPT_WAVE_BATCH, OPT_SPHERE_LDS, OPT_BUILD_ALGO, OPT_REBUILD, OPT_PRESPLIT, OPT_WAVE_BLOCKS, OPT_OVERLAP, OPT_OPTIMIZE, OPT_WAVE_SAMPLES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 24, 25
 
 # every symbol include/ptmi.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32

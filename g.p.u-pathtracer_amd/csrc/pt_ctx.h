@@ -75,6 +75,7 @@ struct pt_ctx {
     void* d_wave = nullptr;
     size_t wave_bytes = 0;
     int opt_wave_batch = 16;     // extend kernel: finished lanes that make a wave leave the walk to write hits / refill
+    int opt_wave_samples = 16;   // bounce 0 of the stage-split pipeline: samples of one pixel per wave (PT_OPT_WAVE_SAMPLES)
     int opt_wave_blocks = 8;     // extend kernel: resident 256-thread blocks per CU the grid is sized for (PT_OPT_WAVE_BLOCKS)
     // PT_KERNEL_AUTO: which stage layout is faster depends on the workload (long paths and many samples per call:
     // the stage-split pipeline; short paths or few samples: the persistent kernel), so the first FOUR calls of a
@@ -169,6 +170,13 @@ hipError_t launch_persist(const LaunchCfg& L, const KParams& P, hipStream_t st);
 hipError_t launch_fold(const KParams& P, hipStream_t st);                            // pt_k_persist.hip
 // stage-split pipeline (pt_k_wave.hip): generate -> depth x (extend, shade) ; returns PT_* status
 int render_wavefront(pt_ctx* c, KParams& P, const LaunchCfg& L, int work_tiles);
+// samples of one pixel that share a wave at bounce 0 of the stage-split pipeline, as a power of two (wf_slot_pixel): the largest
+// 2^k <= PT_OPT_WAVE_SAMPLES, k >= 2, that divides spp; else 0 (one sample of a whole tile per wave, the other kernels' order)
+inline uint32_t wave_sample_group_log2(uint32_t spp, int cap) {
+    for (int k = 6; k >= 2; k--)
+        if ((1 << k) <= cap && (spp & ((1u << k) - 1u)) == 0u) return (uint32_t)k;
+    return 0u;
+}
 int wave_reserve(pt_ctx* c, const KParams& P, int work_tiles);   // path records for this call, allocated now
 // PT_OPT_TIMING: marks the end of a stage of the running call on the context's stream (no-op when timing is off)
 int stage_mark(pt_ctx* c, int kind_of_work_since_last_mark);

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_mega_bvh2(const KParams
     uint32_t n_done = P.spp;
     if (P.samples) {
         const v3 col = pt_get_sample<COUNT, ALG>(P, px, py, pix, P.frame + s_only, stk, s_top, tc, n_rays, n_hits);
-        float* dst = P.samples + 3 * ((size_t)s_only * (size_t)P.W * (size_t)P.H + (size_t)pix);
+        float* dst = pt_sample_ptr(P, (uint32_t)s_only, (size_t)pix);
         dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
         n_done = 1;
     } else {

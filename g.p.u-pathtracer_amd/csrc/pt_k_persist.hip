@@ -94,17 +94,12 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
             if (phase == PH_IDLE) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (rank < take) {
-                    uint32_t q = chunk_next + rank;
+                    const uint32_t q = chunk_next + rank;
                     uint32_t s_first = 0;
-                    if (P.samples) {  // sample-major slots: [sample][tile][lane]
-                        s_first = q / slots_per_sample;
-                        q -= s_first * slots_per_sample;
-                    }
-                    int tx, ty;
-                    if (pt_tile_coords(P, (int)(q >> 6), tx, ty)) {
-                        const int px = tx * PT_TILE + (int)(q & 7u);
-                        const int py = ty * PT_TILE + (int)((q >> 3) & 7u);
-                        if (px < P.W && py < P.H) {  // tracer.cu:358
+                    int px = 0, py = 0;
+                    // (sample, pixel) of the slot: pt_slot_pixel — [sample][tile][lane], or the samples of a pixel side by side
+                    {
+                        if (pt_slot_pixel(P, q, s_first, px, py)) {   // tracer.cu:358
                             pix = (uint32_t)py * (uint32_t)P.W + (uint32_t)px;
                             s_idx = s_first;
                             // camera ray, then walk (or straight to shading); px/py live only here
@@ -163,7 +158,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                     phase = PH_TRAV;
                 }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
             } else if (P.samples) {
-                float* dst = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+                float* dst = pt_sample_ptr(P, (uint32_t)s_idx, (size_t)pix);
                 pt_sst1(dst, col.x); pt_sst1(dst + 1, col.y); pt_sst1(dst + 2, col.z);   // read once, by the fold
                 if (COUNT) n_paths++;
                 phase = PH_IDLE;
@@ -224,14 +219,60 @@ __global__ void __launch_bounds__(256) k_fold_samples(const KParams P) {
     if (!pt_tile_coords(P, tile, tx, ty)) return;
     const int px = tx * PT_TILE + (lane & 7), py = ty * PT_TILE + (lane >> 3);
     if (px >= P.W || py >= P.H) return;
-    const size_t pix = (size_t)py * (size_t)P.W + (size_t)px, plane = (size_t)P.W * (size_t)P.H;
+    const size_t pix = (size_t)py * (size_t)P.W + (size_t)px;
     float* acc = P.accum + 3 * pix;
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
     for (uint32_t s = 0; s < P.spp; s++) {
-        const float* c = P.samples + 3 * (s * plane + pix);
+        const float* c = pt_sample_ptr(P, s, pix);
         pt_accumulate(ax, ay, az, V3(pt_sld1(c), pt_sld1(c + 1), pt_sld1(c + 2)), P.sample_index + s);
     }
+    acc[0] = ax; acc[1] = ay; acc[2] = az;
+    if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
+}
+
+// The same fold over the stage-split pipeline's [pixel][sample][3] sample buffer (spp a multiple of 4): FOUR lanes per pixel, each
+// reading a quarter of the pixel's samples (adjacent lanes read adjacent bytes: a wave covers two 8-pixel runs of the tile end to
+// end), the running mean handed from quarter to quarter so that the samples enter it in order 0 .. spp-1 exactly as above.
+__global__ void __launch_bounds__(256) k_fold_samples_grouped(const KParams P) {
+    const int tile = blockIdx.x, k = threadIdx.x >> 2, part = threadIdx.x & 3;
+    int tx, ty;
+    if (!pt_tile_coords(P, tile, tx, ty)) return;
+    const int px = tx * PT_TILE + (k & 7), py = ty * PT_TILE + (k >> 3);
+    const bool in = px < P.W && py < P.H;   // the four lanes of a pixel agree
+    const size_t pix = in ? (size_t)py * (size_t)P.W + (size_t)px : 0;
+    float* acc = P.accum + 3 * pix;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (in && P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
+    const uint32_t per = P.spp >> 2, s0 = (uint32_t)part * per;
+    const float* c = pt_sample_ptr(P, s0, pix);
+    // 16 samples per call (the bench step): the quarter's three 16-byte pieces are requested before the hand-over chain starts;
+    // other sizes stream theirs inside their turn
+    const bool pre = per == 4u;
+    float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa, qd = qa;
+    if (in && pre) {
+        const float4* c4 = (const float4*)c;
+        qa = pt_sld4(c4); qb = pt_sld4(c4 + 1); qd = pt_sld4(c4 + 2);
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int turn = 0; turn < 4; turn++) {
+        if (in && part == turn) {
+            if (pre) {
+                pt_accumulate(ax, ay, az, V3(qa.x, qa.y, qa.z), P.sample_index + s0);
+                pt_accumulate(ax, ay, az, V3(qa.w, qb.x, qb.y), P.sample_index + s0 + 1);
+                pt_accumulate(ax, ay, az, V3(qb.z, qb.w, qd.x), P.sample_index + s0 + 2);
+                pt_accumulate(ax, ay, az, V3(qd.y, qd.z, qd.w), P.sample_index + s0 + 3);
+            } else {
+                const float* cc = c;
+                for (uint32_t s = 0; s < per; s++, cc += 3)
+                    pt_accumulate(ax, ay, az, V3(pt_sld1(cc), pt_sld1(cc + 1), pt_sld1(cc + 2)), P.sample_index + s0 + s);
+            }
+        }
+        const int src = (lane & ~3) | turn;   // the quarter that just ran hands the mean on
+        ax = __shfl(ax, src); ay = __shfl(ay, src); az = __shfl(az, src);
+    }
+    if (!in || part != 0) return;
     acc[0] = ax; acc[1] = ay; acc[2] = az;
     if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
 }
@@ -281,7 +322,8 @@ hipError_t launch_persist(const LaunchCfg& L, const KParams& P, hipStream_t st) 
 }
 
 hipError_t launch_fold(const KParams& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_fold_samples, dim3((P.n_tiles + 3) / 4), dim3(256), 0, st, P);
+    if (P.smp_ps > 1u) hipLaunchKernelGGL(k_fold_samples_grouped, dim3(P.n_tiles), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(k_fold_samples, dim3((P.n_tiles + 3) / 4), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 

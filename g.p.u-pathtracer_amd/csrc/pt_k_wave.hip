@@ -68,19 +68,10 @@ __global__ void __launch_bounds__(256) k_wf_prepare(const KParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// slot = region * 256 + thread, in the tile order of the other frame kernels (slot >> 6 = work tile =
-// (sample, tile), slot & 63 = pixel of the 8x8 tile), so a wave's primary rays are coherent.  False for the
-// slots of a partial tile that lie outside the image (tracer.cu:358).
+// slot = region * 256 + thread; slot >> 6 = a wave's worth of bounce-0 paths, coherent by construction (pt_slot_pixel)
 __device__ __forceinline__ bool wf_slot_pixel(const KParams& P, uint32_t slot, uint32_t& s_idx, int& px, int& py) {
     if (slot >= P.wf.n_slots) return false;
-    int wt = (int)(slot >> 6);
-    s_idx = (uint32_t)(wt / P.n_tiles);
-    wt -= (int)s_idx * P.n_tiles;
-    int tx = 0, ty = 0;
-    if (s_idx >= P.spp || !pt_tile_coords(P, wt, tx, ty)) return false;
-    px = tx * PT_TILE + (int)(slot & 7u);
-    py = ty * PT_TILE + (int)((slot >> 3) & 7u);
-    return px < P.W && py < P.H;
+    return pt_slot_pixel(P, slot, s_idx, px, py);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,6 +203,12 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_wf_extend(const KParams P) {
 // shade: one bounce of tracer.cu:98-296 for every live record of a region; see the file header.
 // FIRST: bounce 0 — lane = slot; the path starts here (camera ray, RNG) and the sample colour is written, not added to.
 // LAST: the path's final bounce (without PT_FLAG_NEE): only the hit's emission is still wanted (path_last_emission).
+// where a surviving path's record goes inside its region: packed in slot order (experiments splice their own order in here:
+// tools/pt_exp_hooks.h, PT_EXP_SORT)
+#ifndef PT_SURVIVOR_RANK
+#define PT_SURVIVOR_RANK(P, alive, ps, total, s_cnt) wf_block_rank(alive, total, s_cnt)
+#endif
+
 template <bool COUNT, bool NEE, bool FIRST, bool LAST = false>
 __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
@@ -272,7 +269,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             h.tri = 0;
             if (P.tri_matid) h.tri = __float_as_int(P.sc.nodes[h.rec].w);
         }
-        float* smp = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+        float* smp = pt_sample_ptr(P, s_idx, (size_t)pix);
         const SceneHit sh = pt_closest_sphere(P, ps.o, ps.d, h, 0);
         if (sh.geom == 3) {   // tracer.cu:140-142: the sample IS the background colour, whatever was gathered before
             PT_KARGS(K);
@@ -316,7 +313,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     }
     if (last) return;   // every path ends with this bounce (tracer.cu:305)
     int total;
-    const int r = wf_block_rank(alive, total, s_cnt);
+    const int r = PT_SURVIVOR_RANK(P, alive, ps, total, s_cnt);
     if (alive) {
         const size_t j = (size_t)region * PT_REGION + (size_t)r;
         pt_sst4(P.wf.ray0_out + j, make_float4(ps.o.x, ps.o.y, ps.o.z, ps.d.x));
@@ -340,7 +337,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_resolve(const KParams P) {
     if (hh.x < c.w) return;   // a triangle is in the way
     const float4 b = P.wf.s_ray1[i];
     const uint32_t pix = __float_as_uint(b.z), s_idx = __float_as_uint(b.w);
-    float* smp = P.samples + 3 * ((size_t)s_idx * (size_t)P.W * (size_t)P.H + (size_t)pix);
+    float* smp = pt_sample_ptr(P, s_idx, (size_t)pix);
     smp[0] += c.x; smp[1] += c.y; smp[2] += c.z;
 }
 

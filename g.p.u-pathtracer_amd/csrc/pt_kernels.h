@@ -110,8 +110,18 @@ struct KParams {
     // and folded into the running mean afterwards, in order, by k_fold_samples.  The frame's
     // critical path is then ONE path, not spp paths, and a launch has spp x more parallel work.
     float* __restrict__ samples;   // nullptr: fold each sample straight into accum (spp == 1)
+    // where (sample s, pixel p) lives: samples + 3 * (s * smp_ss + p * smp_ps) — [spp][H*W][3] (W*H, 1) for the kernels whose
+    // waves hold ONE sample of 64 pixels, [H*W][spp][3] (1, spp) for the stage-split pipeline's sample groups
+    unsigned long long smp_ss;
+    uint32_t smp_ps;
+    uint32_t sgroup_log2;          // 64 consecutive (sample, pixel) slots = 2^k samples x (64 >> k) pixels of a tile (pt_slot_pixel)
     KWave wf;
 };
+
+// the three colour floats of (sample s, pixel pix) in the call's sample buffer
+__device__ __forceinline__ float* pt_sample_ptr(const KParams& P, uint32_t s, size_t pix) {
+    return P.samples + 3 * ((size_t)s * (size_t)P.smp_ss + pix * (size_t)P.smp_ps);
+}
 
 struct Hit {
     float t;   // PT_F32_MAX on miss
@@ -224,4 +234,36 @@ __device__ __forceinline__ bool pt_tile_coords(const KParams& P, int tile, int& 
         ty = lrow;
     }
     return ty < P.tile_rows;
+}
+
+// The call's (sample, pixel) slots, 64 to a work tile, n_tiles * spp work tiles (stage-split pipeline and persistent kernel):
+//  * sgroup_log2 = 0: work tile = (sample, tile), slot & 63 = pixel of the 8x8 tile in row order;
+//  * sgroup_log2 = k: G = 2^k samples x 64/G pixels of a tile — the G samples of a pixel are the SAME ray but for the sub-pixel
+//    jitter, so lanes that start them together walk the same nodes and records in step.  Work tile -> (sample group, tile, j-th
+//    share of the tile's pixels); lane -> (pixel number j * 64/G + lane / G in Morton order, sample lane % G).
+// Which lane traces which (pixel, sample) changes no result: every path is keyed by (sample's frame hash, pixel).
+// False for slots past the call's last and for the pixels of a partial tile that lie outside the image (tracer.cu:358).
+__device__ __forceinline__ bool pt_slot_pixel(const KParams& P, uint32_t slot, uint32_t& s_idx, int& px, int& py) {
+    const uint32_t lg = P.sgroup_log2;
+    int wt = (int)(slot >> 6);
+    uint32_t k = slot & 63u, s_in = 0u;
+    if (lg) {
+        const uint32_t g1 = (1u << lg) - 1u;
+        s_in = k & g1;
+        k = ((uint32_t)wt & g1) * (64u >> lg) + (k >> lg);
+        wt >>= lg;
+    }
+    const uint32_t grp = (uint32_t)(wt / P.n_tiles);
+    wt -= (int)grp * P.n_tiles;
+    s_idx = (grp << lg) + s_in;
+    int tx = 0, ty = 0;
+    if (s_idx >= P.spp || !pt_tile_coords(P, wt, tx, ty)) return false;
+    if (lg) {   // Morton order inside the tile: consecutive pixel numbers form 2x2, 4x2, 4x4 ... blocks
+        px = tx * PT_TILE + (int)((k & 1u) | ((k >> 1) & 2u) | ((k >> 2) & 4u));
+        py = ty * PT_TILE + (int)(((k >> 1) & 1u) | ((k >> 2) & 2u) | ((k >> 3) & 4u));
+    } else {
+        px = tx * PT_TILE + (int)(k & 7u);
+        py = ty * PT_TILE + (int)((k >> 3) & 7u);
+    }
+    return px < P.W && py < P.H;
 }

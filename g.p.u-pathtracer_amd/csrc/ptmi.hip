@@ -288,6 +288,10 @@ int pt_set_option(pt_ctx* c, int option, int value) {
             if (value < 0 || value > 16) return fail(c, PT_ERR_INVALID, "pt_set_option: optimize passes must be 0 (off) .. 16");
             c->opt_optimize = value;   // takes effect at the next pt_upload_bvh
             return PT_OK;
+        case PT_OPT_WAVE_SAMPLES:
+            if (value < 1 || value > 64) return fail(c, PT_ERR_INVALID, "pt_set_option: wave samples must be 1 (one sample of a tile per wave) .. 64");
+            c->opt_wave_samples = value;
+            return PT_OK;
         case PT_OPT_WAVE_BLOCKS:
             if (value < 1 || value > 8) return fail(c, PT_ERR_INVALID, "pt_set_option: wave blocks must be 1..8 per CU");
             c->opt_wave_blocks = value;
@@ -749,6 +753,16 @@ int pt_render(pt_ctx* c, float* accum_dev, uint32_t* rgba_dev, const pt_camera* 
             have = need;
         }
         P.samples = buf;
+    }
+    P.smp_ss = (unsigned long long)p->width * (unsigned long long)p->height;
+    P.smp_ps = 1u;
+    P.sgroup_log2 = 0u;
+    if (P.samples && (wavefront || persistent)) {   // the samples of a pixel side by side in the slot order and in the sample buffer
+        P.sgroup_log2 = wave_sample_group_log2(spp, c->opt_wave_samples);
+        if (P.sgroup_log2) {
+            P.smp_ss = 1ull;
+            P.smp_ps = spp;
+        }
     }
     const int work_tiles = P.n_tiles * (P.samples ? (int)spp : 1);
     // the stream the path kernel runs on: it may start once the caller's earlier work has been SUBMITTED, needs the

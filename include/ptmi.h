@@ -155,6 +155,11 @@ enum {
     PT_OPT_WAVE_BLOCKS = 19,  /* PT_KERNEL_WAVEFRONT, extend stage: resident 256-thread blocks per CU its persistent grid is
                                  sized for, 1..8 (default 8 = 8 waves per SIMD); fewer leave room for another
                                  context's launches on the same device                                 */
+    PT_OPT_WAVE_SAMPLES = 25, /* PT_KERNEL_WAVEFRONT, bounce 0: how many samples of ONE pixel share a wave — the largest power of two
+                                 <= this value (4 .. 64) that divides the call's spp; 16 by default (a wave = 16 samples x a 2x2
+                                 pixel block: the samples of a pixel are the same ray but for the sub-pixel jitter, so they walk the
+                                 same nodes and records in step), 1 = one sample of a whole 8x8 tile per wave as in the other
+                                 kernels.  A speed knob: which lane traces which (pixel, sample) changes no result       */
     PT_OPT_OVERLAP = 21,      /* 1 (default): the path kernel of a pt_render call (persistent / mega kernels) runs on a
                                  stream of the context's own, so that it can start while the PREVIOUS call's last paths
                                  drain; the fold into the accumulator stays on the caller's stream, in call order.  When

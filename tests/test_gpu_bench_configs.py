@@ -12,7 +12,7 @@ import pytest
 
 import gpu_pathtracer_amd as g
 import orc
-from test_gpu_parity import gpu_render, l2, bvh_of
+from test_gpu_parity import gpu_render, golden_camera, l2, bvh_of
 
 pytestmark = pytest.mark.gpu
 
@@ -125,6 +125,45 @@ def test_one_spp_calls_equal_one_multi_spp_call(ptd):
     acc.free()
     rgba.free()
     assert np.array_equal(one, many)
+
+
+@pytest.mark.parametrize("kernel", [g.KERNEL_WAVEFRONT, g.KERNEL_PERSISTENT], ids=["wavefront", "persistent"])
+def test_wave_sample_groups_change_no_pixel(kernel):
+    """PT_OPT_WAVE_SAMPLES decides which lane of the stage-split pipeline / the persistent kernel traces which (pixel, sample) — 16 samples of a 2x2 pixel
+    block per wave by default, a whole 8x8 tile of one sample with 1 — and which layout the sample buffer has; the accumulator and
+    the display words must not depend on it: ragged image, a tile split, spp that 16 / 8 / 4 divide and one that nothing does,
+    next-event estimation (its shadow records carry the sample number), a second call on top of the first (running mean)."""
+    _, bvh = bvh_of("cornell_dragon")
+    sph = g.reference_spheres()
+    for (W, H), spp, flags, parts in (((333, 187), 16, 0, 1), ((640, 360), 8, 0, 3), ((640, 360), 12, g.FLAG_NEE | g.FLAG_COSINE_DIFF, 1),
+                                      ((333, 187), 5, 0, 1), ((256, 256), 64, 0, 1)):
+        cam = golden_camera(W, H)
+        frames = {}
+        for cap in (1, 4, 16, 64):
+            t = g.PathTracer(0)
+            try:
+                t.set_option(g.OPT_KERNEL, kernel)
+                t.set_option(g.OPT_WAVE_SAMPLES, cap)
+                t.upload_bvh(bvh)
+                t.upload_spheres(sph)
+                acc, rgba = t.alloc_frame(W, H)
+                for call in range(2):
+                    for part in range(parts):
+                        p = g.default_params(W, H)
+                        p.flags = flags | g.FLAG_WRITE_RGBA
+                        p.frame, p.sample_index = 7 + call * spp, 1 + call * spp
+                        p.part_index, p.part_count, p.part_rows = part, parts, 8
+                        t.launch_kernel(acc.ptr, rgba.ptr, cam, p, spp)
+                t.sync()
+                frames[cap] = (acc.download(np.float32, (H, W, 3)), rgba.download(np.uint32, (H, W)))
+                acc.free()
+                rgba.free()
+            finally:
+                t.close()
+        for cap in (4, 16, 64):
+            assert np.array_equal(frames[cap][0], frames[1][0]), (W, H, spp, cap)
+            assert np.array_equal(frames[cap][1], frames[1][1]), (W, H, spp, cap)
+        assert frames[1][0].any()
 
 
 def test_auto_times_both_layouts_and_keeps_one():

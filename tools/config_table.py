@@ -10,6 +10,8 @@ import gpu_pathtracer_amd as g
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=10)
+ap.add_argument("--optimize", type=int, default=3, help="PT_OPT_OPTIMIZE passes at upload (0 = the trees of rounds 1-2)")
+ap.add_argument("--wave-samples", type=int, default=0, help="PT_OPT_WAVE_SAMPLES (0 = the default; 1 = one sample of a tile per wave)")
 a = ap.parse_args()
 
 CONFIGS = [
@@ -34,6 +36,9 @@ for name, scene, W, H, spp, mat, spheres in CONFIGS:
         pt = g.PathTracer(0)
         pt.set_option(g.OPT_KERNEL, kern)
         pt.set_option(g.OPT_REBUILD, 2)      # as bench.py uploads: keep the tree with fewer node visits
+        pt.set_option(g.OPT_OPTIMIZE, a.optimize)
+        if a.wave_samples:
+            pt.set_option(g.OPT_WAVE_SAMPLES, a.wave_samples)
         pt.upload_bvh(bvh)
         pt.upload_spheres(g.reference_spheres() if spheres else None)
         cam = g.default_camera(W, H)

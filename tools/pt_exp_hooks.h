@@ -38,3 +38,60 @@
           asm volatile("global_load_dword %0, %1, off" : "+v"(touch_) : "v"(tp_) : "memory"); } }
 #define PT_WALK_EXIT_HOOK() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); asm volatile("" : "+v"(touch_)); }
 #endif
+
+#if defined(PT_EXP_SORT)
+#include <hip/hip_runtime.h>
+// Ray ordering at the shade stage's compaction: the survivors of a region (256 paths) are packed by
+// (cell of the new ray's origin in a PT_EXP_SORT^3 grid over the scene's bounds, octant of its direction) instead of slot order —
+// a counting sort in LDS (atomics: the order INSIDE a bin is arbitrary; no result depends on where a record sits).
+template <class KP, class PS>
+__device__ __forceinline__ int exp_rank_sorted(const KP& P, bool alive, const PS& ps, int& total) {
+    constexpr int C = PT_EXP_SORT, B = C * C * C * 8, PER = (B + 255) / 256;
+    __shared__ int s_hist[B];
+    __shared__ int s_wave[4];
+    for (int b = threadIdx.x; b < B; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    int key = 0, my = 0;
+    if (alive) {
+        const float4 q0 = P.sc.nodes[P.sc.wide_root], q3 = P.sc.nodes[P.sc.wide_root + 3];   // origin and grid step (x 255 = extent)
+        const int cx = min(C - 1, max(0, (int)((ps.o.x - q0.x) / (q0.w * 255.f) * (float)C)));
+        const int cy = min(C - 1, max(0, (int)((ps.o.y - q0.y) / (q3.z * 255.f) * (float)C)));
+        const int cz = min(C - 1, max(0, (int)((ps.o.z - q0.z) / (q3.w * 255.f) * (float)C)));
+        const int oct = (ps.d.x < 0.f ? 1 : 0) | (ps.d.y < 0.f ? 2 : 0) | (ps.d.z < 0.f ? 4 : 0);
+        key = ((cz * C + cy) * C + cx) * 8 + oct;
+        my = atomicAdd(&s_hist[key], 1);
+    }
+    __syncthreads();
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int b = (int)threadIdx.x * PER + k;
+        loc[k] = sum;
+        sum += b < B ? s_hist[b] : 0;
+    }
+    int inc = sum;   // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(inc, d);
+        if ((int)(threadIdx.x & 63) >= d) inc += v;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = inc - sum, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < (int)(threadIdx.x >> 6)) base += s_wave[w];
+        tot += s_wave[w];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int b = (int)threadIdx.x * PER + k;
+        if (b < B) s_hist[b] = base + loc[k];
+    }
+    __syncthreads();
+    total = tot;
+    return s_hist[key] + my;
+}
+#define PT_SURVIVOR_RANK(P, alive, ps, total, s_cnt) exp_rank_sorted(P, alive, ps, total)
+#endif

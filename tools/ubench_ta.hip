@@ -6,6 +6,8 @@
 //   mode 2: every aligned group of 8 lanes one random 128-byte line (8 lines per instruction)
 //   mode 3: all 64 lanes one contiguous 1 KB (fully coalesced)
 //   mode 4 / 5 / 6: as mode 0 with dwordx2 / dword / dwordx3 loads (is the cost per lane or per byte?)
+//   mode 7 / 8 / 9: as mode 0 with 48 / 32 / 16 of the 64 lanes active, scattered over the wave (is the cost per instruction or
+//                   per ACTIVE lane?  a walk's load instructions run at 0.5-0.7 of the lanes)
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_ta tools/ubench_ta.hip ; run: tools/ubench_ta [n_items]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -17,7 +19,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
     return x;
 }
 
-template <int MODE>
+template <int MODE, int ACTIVE = 64>
 __global__ void __launch_bounds__(256, 8) k_ta(const float4* __restrict__ items, uint32_t n_items, int iters, float* out) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
@@ -26,6 +28,7 @@ __global__ void __launch_bounds__(256, 8) k_ta(const float4* __restrict__ items,
     const uint32_t span = MODE == 3 ? 16 : (MODE == 2 ? 2 : 1);   // items per group line
     float acc = 0.f;
     uint32_t s = mix(group * 2654435761u + 99u);
+    if (ACTIVE < 64 && ((lane * 37u) & 63u) >= (uint32_t)ACTIVE) { out[gid] = 0.f; return; }   // 37 is odd: a permutation of the lanes
     for (int it = 0; it < iters; it++) {
         float4 q[8];
 #pragma unroll
@@ -53,7 +56,7 @@ int main(int argc, char** argv) {
     hipMalloc(&d_out, (size_t)blocks * threads * 4);
     hipMemcpy(d_items, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 7; mode++) {
+    for (int mode = 0; mode < 10; mode++) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             hipEventRecord(e0);
@@ -63,6 +66,9 @@ int main(int argc, char** argv) {
             else if (mode == 4) hipLaunchKernelGGL(k_ta<4>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 5) hipLaunchKernelGGL(k_ta<5>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else if (mode == 6) hipLaunchKernelGGL(k_ta<6>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 7) hipLaunchKernelGGL((k_ta<0, 48>), dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 8) hipLaunchKernelGGL((k_ta<0, 32>), dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
+            else if (mode == 9) hipLaunchKernelGGL((k_ta<0, 16>), dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             else hipLaunchKernelGGL(k_ta<3>, dim3(blocks), dim3(threads), 0, 0, d_items, n_items, iters, d_out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);

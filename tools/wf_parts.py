@@ -16,6 +16,7 @@ keep = False
 bvh_kw = {}
 rebuild = None
 optimize = 0
+wave_samples = None
 while args:
     a = args.pop(0)
     if a == "--scene": scene = args.pop(0)
@@ -32,6 +33,7 @@ while args:
             bvh_kw[k] = float(v) if k in ("split_alpha", "sah_node_cost", "sah_tri_cost") else int(v)
     elif a == "--rebuild": rebuild = int(args.pop(0))
     elif a == "--optimize": optimize = int(args.pop(0))   # PT_OPT_OPTIMIZE passes at upload
+    elif a == "--wave-samples": wave_samples = int(args.pop(0))   # PT_OPT_WAVE_SAMPLES (1 = a whole tile of one sample per wave)
     else: cfgs.append(tuple(int(x) for x in a.split(":")))
 W, H = 1920, 1080
 pt = g.PathTracer(0)
@@ -41,6 +43,8 @@ if node_width is not None:   # the 8-wide experiment (commit aada2a3: profiles/r
     pt.set_option(23, node_width)
 if occ is not None:
     pt.set_option(g.OPT_OCCUPANCY, occ)
+if wave_samples is not None:
+    pt.set_option(g.OPT_WAVE_SAMPLES, wave_samples)
 t0 = time.perf_counter()
 if dev_build:
     pt.set_option(g.OPT_OPTIMIZE, optimize)
