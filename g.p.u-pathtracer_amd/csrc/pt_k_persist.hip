@@ -231,46 +231,45 @@ __global__ void __launch_bounds__(256) k_fold_samples(const KParams P) {
     if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);
 }
 
-// The same fold over the stage-split pipeline's [pixel][sample][3] sample buffer (spp a multiple of 4): FOUR lanes per pixel, each
-// reading a quarter of the pixel's samples (adjacent lanes read adjacent bytes: a wave covers two 8-pixel runs of the tile end to
-// end), the running mean handed from quarter to quarter so that the samples enter it in order 0 .. spp-1 exactly as above.
+// The same fold over the [pixel][sample][3] sample buffer of the sample groups (spp a multiple of 4): LP lanes per pixel, each
+// reading spp / LP consecutive samples in 16-byte pieces (four samples = three pieces; adjacent lanes read adjacent bytes, so a
+// wave covers whole 8-pixel runs of its tile end to end), the running mean handed from lane to lane so that the samples enter it
+// in order 0 .. spp-1 exactly as above.  LP = 4 for 16 samples per call, 2 for 8, 1 for 4 (largest of 4 / 2 / 1 dividing spp / 4).
+template <int LP>
 __global__ void __launch_bounds__(256) k_fold_samples_grouped(const KParams P) {
-    const int tile = blockIdx.x, k = threadIdx.x >> 2, part = threadIdx.x & 3;
-    int tx, ty;
-    if (!pt_tile_coords(P, tile, tx, ty)) return;
-    const int px = tx * PT_TILE + (k & 7), py = ty * PT_TILE + (k >> 3);
-    const bool in = px < P.W && py < P.H;   // the four lanes of a pixel agree
+    const int k = threadIdx.x / LP, part = threadIdx.x % LP;
+    const int tile = blockIdx.x * (4 / LP) + (k >> 6);
+    int tx = 0, ty = 0;
+    const bool have_tile = pt_tile_coords(P, tile, tx, ty);   // the LP lanes of a pixel agree; nobody leaves before the last hand-over
+    const int px = tx * PT_TILE + (k & 7), py = ty * PT_TILE + ((k >> 3) & 7);
+    const bool in = have_tile && px < P.W && py < P.H;
     const size_t pix = in ? (size_t)py * (size_t)P.W + (size_t)px : 0;
     float* acc = P.accum + 3 * pix;
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (in && P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
-    const uint32_t per = P.spp >> 2, s0 = (uint32_t)part * per;
-    const float* c = pt_sample_ptr(P, s0, pix);
-    // 16 samples per call (the bench step): the quarter's three 16-byte pieces are requested before the hand-over chain starts;
-    // other sizes stream theirs inside their turn
+    const uint32_t per = P.spp / (uint32_t)LP, s0 = (uint32_t)part * per;   // a multiple of 4 samples
+    const float4* c4 = (const float4*)pt_sample_ptr(P, s0, pix);
+    // one group of four (the 16-, 8- and 4-sample calls): requested before the hand-over chain starts; longer shares stream theirs
+    // inside their turn
     const bool pre = per == 4u;
     float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa, qd = qa;
-    if (in && pre) {
-        const float4* c4 = (const float4*)c;
-        qa = pt_sld4(c4); qb = pt_sld4(c4 + 1); qd = pt_sld4(c4 + 2);
-    }
+    if (in && pre) { qa = pt_sld4(c4); qb = pt_sld4(c4 + 1); qd = pt_sld4(c4 + 2); }
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int turn = 0; turn < 4; turn++) {
+    for (int turn = 0; turn < LP; turn++) {
         if (in && part == turn) {
-            if (pre) {
-                pt_accumulate(ax, ay, az, V3(qa.x, qa.y, qa.z), P.sample_index + s0);
-                pt_accumulate(ax, ay, az, V3(qa.w, qb.x, qb.y), P.sample_index + s0 + 1);
-                pt_accumulate(ax, ay, az, V3(qb.z, qb.w, qd.x), P.sample_index + s0 + 2);
-                pt_accumulate(ax, ay, az, V3(qd.y, qd.z, qd.w), P.sample_index + s0 + 3);
-            } else {
-                const float* cc = c;
-                for (uint32_t s = 0; s < per; s++, cc += 3)
-                    pt_accumulate(ax, ay, az, V3(pt_sld1(cc), pt_sld1(cc + 1), pt_sld1(cc + 2)), P.sample_index + s0 + s);
+            for (uint32_t s = 0; s < per; s += 4, c4 += 3) {
+                if (!pre) { qa = pt_sld4(c4); qb = pt_sld4(c4 + 1); qd = pt_sld4(c4 + 2); }
+                pt_accumulate(ax, ay, az, V3(qa.x, qa.y, qa.z), P.sample_index + s0 + s);
+                pt_accumulate(ax, ay, az, V3(qa.w, qb.x, qb.y), P.sample_index + s0 + s + 1);
+                pt_accumulate(ax, ay, az, V3(qb.z, qb.w, qd.x), P.sample_index + s0 + s + 2);
+                pt_accumulate(ax, ay, az, V3(qd.y, qd.z, qd.w), P.sample_index + s0 + s + 3);
             }
         }
-        const int src = (lane & ~3) | turn;   // the quarter that just ran hands the mean on
-        ax = __shfl(ax, src); ay = __shfl(ay, src); az = __shfl(az, src);
+        if (LP > 1) {   // the share that just ran hands the mean on
+            const int src = (lane & ~(LP - 1)) | turn;
+            ax = __shfl(ax, src); ay = __shfl(ay, src); az = __shfl(az, src);
+        }
     }
     if (!in || part != 0) return;
     acc[0] = ax; acc[1] = ay; acc[2] = az;
@@ -322,8 +321,12 @@ hipError_t launch_persist(const LaunchCfg& L, const KParams& P, hipStream_t st) 
 }
 
 hipError_t launch_fold(const KParams& P, hipStream_t st) {
-    if (P.smp_ps > 1u) hipLaunchKernelGGL(k_fold_samples_grouped, dim3(P.n_tiles), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL(k_fold_samples, dim3((P.n_tiles + 3) / 4), dim3(256), 0, st, P);
+    if (P.smp_ps > 1u) {   // sample groups: spp is a multiple of 4
+        const uint32_t q = P.spp / 4u;
+        if ((q & 3u) == 0u) hipLaunchKernelGGL(k_fold_samples_grouped<4>, dim3(P.n_tiles), dim3(256), 0, st, P);
+        else if ((q & 1u) == 0u) hipLaunchKernelGGL(k_fold_samples_grouped<2>, dim3((P.n_tiles + 1) / 2), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL(k_fold_samples_grouped<1>, dim3((P.n_tiles + 3) / 4), dim3(256), 0, st, P);
+    } else hipLaunchKernelGGL(k_fold_samples, dim3((P.n_tiles + 3) / 4), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ import gpu_pathtracer_amd as g
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=10)
+ap.add_argument("--only", default="", help="comma-separated substrings: run the configurations whose name holds one of them")
 ap.add_argument("--optimize", type=int, default=3, help="PT_OPT_OPTIMIZE passes at upload (0 = the trees of rounds 1-2)")
 ap.add_argument("--wave-samples", type=int, default=0, help="PT_OPT_WAVE_SAMPLES (0 = the default; 1 = one sample of a tile per wave)")
 a = ap.parse_args()
@@ -30,6 +31,8 @@ CONFIGS = [
 ]
 print(f"{'configuration':62s} {'kernel':>10s} {'ms/call':>9s} {'Msegments':>10s} {'Mrays/s':>9s}")
 for name, scene, W, H, spp, mat, spheres in CONFIGS:
+    if a.only and not any(k in name for k in a.only.split(",")):
+        continue
     mesh = g.scene_mesh(scene)
     bvh = g.Bvh(mesh)
     for kname, kern in (("persistent", g.KERNEL_PERSISTENT), ("wavefront", g.KERNEL_WAVEFRONT)):
