@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(PT_BLOCK, OCC) k_trace_persist_bvh2(const KPar
                 }  // else: stays PH_SHADE with the (miss) hit record, shaded again next round
             } else if (P.samples) {
                 float* dst = pt_sample_ptr(P, (uint32_t)s_idx, (size_t)pix);
-                pt_sst1(dst, col.x); pt_sst1(dst + 1, col.y); pt_sst1(dst + 2, col.z);   // read once, by the fold
+                pt_sst3(dst, col);   // read once, by the fold
                 if (COUNT) n_paths++;
                 phase = PH_IDLE;
             } else {
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) k_fold_samples(const KParams P) {
     if (P.sample_index != 1) { ax = acc[0]; ay = acc[1]; az = acc[2]; }
     for (uint32_t s = 0; s < P.spp; s++) {
         const float* c = pt_sample_ptr(P, s, pix);
-        pt_accumulate(ax, ay, az, V3(pt_sld1(c), pt_sld1(c + 1), pt_sld1(c + 2)), P.sample_index + s);
+        pt_accumulate(ax, ay, az, pt_sld3(c), P.sample_index + s);
     }
     acc[0] = ax; acc[1] = ay; acc[2] = az;
     if ((P.flags & PT_FLAG_WRITE_RGBA) && P.rgba) P.rgba[pix] = pt_pack_rgba(ax, ay, az);

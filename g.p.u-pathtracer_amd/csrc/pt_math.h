@@ -90,6 +90,34 @@ __device__ __forceinline__ void pt_sst1(float* p, float a) {
 #endif
 }
 
+// three floats (a sample colour: 12-byte stride) as ONE dwordx3 access
+typedef float pt_v3u __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ v3 pt_sld3(const float* p) {
+#if PT_STREAM_NT
+    const pt_v3u v = __builtin_nontemporal_load((const pt_v3u*)p);
+#else
+    const pt_v3u v = *(const pt_v3u*)p;
+#endif
+    return V3(v.x, v.y, v.z);
+}
+// ... and the same without the streaming hint (a sample colour that is added to again within the call)
+__device__ __forceinline__ v3 pt_ld3(const float* p) {
+    const pt_v3u v = *(const pt_v3u*)p;
+    return V3(v.x, v.y, v.z);
+}
+__device__ __forceinline__ void pt_st3(float* p, v3 a) {
+    const pt_v3u v = {a.x, a.y, a.z};
+    *(pt_v3u*)p = v;
+}
+__device__ __forceinline__ void pt_sst3(float* p, v3 a) {
+    const pt_v3u v = {a.x, a.y, a.z};
+#if PT_STREAM_NT
+    __builtin_nontemporal_store(v, (pt_v3u*)p);
+#else
+    *(pt_v3u*)p = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------- RNG
 // uf::hash, GpuPathTracer/utilfun.cpp:380-389
 __device__ __forceinline__ uint64_t pt_wang64(uint64_t key) {
