@@ -288,8 +288,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
             if (FIRST) {   // accu = 0 (tracer.cu:48) + this hit's emission
                 pt_sst3(smp, V3(0.f + e.x, 0.f + e.y, 0.f + e.z));
             } else if (!(e.x == 0.f) || !(e.y == 0.f) || !(e.z == 0.f)) {
-                const v3 s0 = pt_ld3(smp);   // one dwordx3 each way
-                pt_st3(smp, V3(s0.x + e.x, s0.y + e.y, s0.z + e.z));
+                smp[0] += e.x; smp[1] += e.y; smp[2] += e.z;   // (as ONE dwordx3 each way: the last bounce's launch +6 %)
             }
             alive = !done;
         }
@@ -339,8 +338,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_wf_resolve(const KParams P) {
     const float4 b = P.wf.s_ray1[i];
     const uint32_t pix = __float_as_uint(b.z), s_idx = __float_as_uint(b.w);
     float* smp = pt_sample_ptr(P, s_idx, (size_t)pix);
-    const v3 s0 = pt_ld3(smp);
-    pt_st3(smp, V3(s0.x + c.x, s0.y + c.y, s0.z + c.z));
+    smp[0] += c.x; smp[1] += c.y; smp[2] += c.z;
 }
 
 namespace ptmi {

@@ -100,15 +100,6 @@ __device__ __forceinline__ v3 pt_sld3(const float* p) {
 #endif
     return V3(v.x, v.y, v.z);
 }
-// ... and the same without the streaming hint (a sample colour that is added to again within the call)
-__device__ __forceinline__ v3 pt_ld3(const float* p) {
-    const pt_v3u v = *(const pt_v3u*)p;
-    return V3(v.x, v.y, v.z);
-}
-__device__ __forceinline__ void pt_st3(float* p, v3 a) {
-    const pt_v3u v = {a.x, a.y, a.z};
-    *(pt_v3u*)p = v;
-}
 __device__ __forceinline__ void pt_sst3(float* p, v3 a) {
     const pt_v3u v = {a.x, a.y, a.z};
 #if PT_STREAM_NT
