@@ -36,4 +36,13 @@ for rnd in range(2):
         launch(13); pt.sync(); launch(14); pt.sync()
         st = pt.stage_ms()
         print(f"round {rnd} wave-samples {cap:2d}: {ms:7.3f} ms/call  stages " + " ".join(f"{k} {v:.3f}" for k, v in st.items() if v > 0), flush=True)
+        if rnd == 0 and os.environ.get("PT_STATS"):   # instrumented replay: wave-level iterations of each phase and the lanes active in them
+            pt.set_option(g.OPT_TIMING, 0)
+            pt.set_option(g.OPT_COUNTERS, 1)
+            launch(15); pt.sync()
+            c, w = pt.counters(), pt.wave_stats()
+            print("   counters", c)
+            print("   wave stats", w, f"| per ray: loop iterations x64 {64 * w['it_loop'] / c['rays']:.2f}, node steps x64 {64 * w['it_node'] / c['rays']:.2f} "
+                  f"(lane use {w['act_node'] / max(1, 64 * w['it_node']):.2f}), record steps x64 {64 * w['it_rec'] / c['rays']:.2f}, begin x64 {64 * w['it_begin'] / max(1, c['rays']):.2f}", flush=True)
+            pt.set_option(g.OPT_COUNTERS, 0)
         acc.free(); rgba.free(); pt.close()
