@@ -22,7 +22,7 @@ n_launch = 0
 for r in range(a.rounds):
     scene = list(scenes)[r % len(scenes)]
     W, H = int(rng.integers(2, 900)), int(rng.integers(2, 700))
-    spp = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    spp = int(rng.choice([1, 1, 2, 3, 4, 5, 8, 12, 16]))   # 4, 8, 12, 16: sample groups of 4 / 8 / 4 / 16 (PT_OPT_WAVE_SAMPLES)
     mat = int(rng.integers(0, 4))
     spheres = bool(rng.integers(0, 4))
     parts = int(rng.choice([1, 1, 2, 3]))
