@@ -213,15 +213,15 @@ template <bool COUNT, bool NEE, bool FIRST, bool LAST = false>
 __global__ void __launch_bounds__(PT_BLOCK) k_wf_shade(const KParams P) {
     __shared__ int s_cnt[PT_BLOCK / 64];
     __shared__ int s_cnt2[PT_BLOCK / 64];
-    wf_sphere_table();
     const uint32_t region = blockIdx.x;
     const int n_in = FIRST ? PT_REGION : P.wf.cnt_in[region];
     const bool last = LAST || P.wf.bounce + 1 >= P.depth;
-    if (n_in == 0) {
+    if (n_in == 0) {   // (the whole block: before anything is set up — in an open scene most regions are empty after the first bounce)
         if (!last && threadIdx.x == 0) P.wf.cnt_out[region] = 0;
         if (NEE && threadIdx.x == 0) P.wf.s_cnt[region] = 0;
         return;
     }
+    wf_sphere_table();
     const size_t i = (size_t)region * PT_REGION + threadIdx.x;
     bool have = (int)threadIdx.x < n_in;
     bool alive = false, tri_hit = false;
